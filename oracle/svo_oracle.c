@@ -1,0 +1,623 @@
+/*
+ * svo_oracle.c -- TEST INFRASTRUCTURE.  CPU restatement of the reference's hot path
+ * (the compute shader /root/reference/src/shaders/svotrace.comp), single-threaded,
+ * plain C.  It is the CHECKER for the HIP path: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path never calls it.
+ *
+ * Parity pin: this file is validated bit-for-bit (rgba8, depth bits, hit pointer,
+ * value, raw normal, level, iteration count) against the reference shader itself,
+ * executed unmodified by Mesa llvmpipe through oracle/llvmpipe_ref.c; the resulting
+ * golden vectors are committed under tests/golden/ (tests/golden/make_golden.py).
+ *
+ * It deliberately keeps the reference's STRUCTURE (one byte fetch at a time, the
+ * while-loop child offset walk, the 24-entry stack) so that it shares no code and no
+ * shortcuts with the optimised device kernels it checks.
+ *
+ * Float semantics GLSL leaves open are pinned to what the llvmpipe run does
+ * (SURVEY.md Appendix B/C): IEEE binary32, no contraction (build with
+ * -ffp-contract=off), mix = x + t*(y-x), dot3 = x*a + (y*b + z*c),
+ * normalize = v * (1/sqrt(dot)), min/max ignore NaN (fminf/fmaxf), sign(NaN)=0,
+ * transcendental algorithms of Appendix C with explicit fmaf where they fuse.
+ *
+ * Reference map (file:line in /root/reference/src/shaders/svotrace.comp):
+ *   get_byte            :75-79      extract_*          :88-130
+ *   extract_child       :132-157    intersect_octree   :211-432
+ *   glsl_rand           :26-29      trace              :435-646
+ *   pixel (main)        :649-729
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define EPSILON 3.552713678800501e-15f
+#define PI_F 3.14159265359f
+#define SQRT3_F 1.73205080757f
+#define NODE_SIZE 7u
+#define LEAF_SIZE 3u
+#define NON_SURFACE_LEAF_SIZE 1u
+#define MAX_SCALE 23
+#define MAX_DEPTH 13
+#define MAX_RAYCAST_ITERATIONS 1500u
+
+typedef struct svo_hit {
+  uint32_t pointer;    /* byte offset of the hit node; 0 = miss */
+  uint16_t raw_normal; /* leafMask field of the hit node (packed normal for tag-1 leaves) */
+  uint8_t value;
+  uint8_t level;       /* MAX_SCALE - scale */
+  uint32_t iter;
+  float t;
+} svo_hit;
+
+typedef struct svo_oracle_params {
+  int32_t width, height;
+  float cam[15]; /* pos, l1, l2, r1, r2 (Camera.java:142-151) */
+  int32_t frame_number, render_mode, buffer_end, use_beam;
+  int32_t bounces;      /* path segments in mode 0; reference live value 2 (svotrace.comp:444) */
+  uint32_t mirror_mask; /* bit v set: material v reflects specularly (dormant svotrace.comp:500-504) */
+  int32_t spp;          /* samples per pixel (dormant SAMPLES loop, svotrace.comp:668-670); live value 1 */
+} svo_oracle_params;
+
+typedef struct svo_oracle_stats {
+  uint64_t pixels;
+  uint64_t rays;       /* intersectOctree casts, all-NaN rays excluded */
+  uint64_t nan_rays;   /* casts whose origin or direction is entirely NaN (quirk Q7) */
+  uint64_t iterations; /* loop iterations of counted rays */
+  uint64_t alg_bytes;  /* 7 per cast (root record) + size of every fetched child record */
+} svo_oracle_stats;
+
+typedef struct { float x, y, z; } vec3;
+
+typedef struct {
+  const uint8_t *pool;
+  uint64_t len;
+  svo_oracle_stats *st;
+  int cur_nan;
+} ctx_t;
+
+/* ------------------------------------------------------------------ GLSL helpers */
+
+static inline float gmin(float a, float b) { return fminf(a, b); }
+static inline float gmax(float a, float b) { return fmaxf(a, b); }
+static inline float gsign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float gmix(float x, float y, float t) { return x + t * (y - x); }
+static inline float dot3(vec3 a, vec3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+static inline vec3 v3(float x, float y, float z) { vec3 v = {x, y, z}; return v; }
+static inline vec3 vscale(vec3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline vec3 vadd(vec3 a, vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline vec3 vmul(vec3 a, vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline vec3 gnormalize(vec3 v) {
+  float s = dot3(v, v);
+  float r = 1.0f / sqrtf(s);
+  return vscale(v, r);
+}
+static inline vec3 gcross(vec3 a, vec3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline int find_msb(uint32_t v) { return v ? 31 - __builtin_clz(v) : -1; }
+
+/* llvmpipe's sin/cos: Cephes-style, 3-step Cody-Waite with fma */
+static float sincos_core(float x, int want_cos) {
+  float ax = fabsf(x);
+  float y = ax * 1.27323954473516f;
+  int j = (int)y;
+  j = (j + 1) & ~1;
+  y = (float)j;
+  float r = fmaf(y, -0.78515625f, ax);
+  r = fmaf(y, -2.4187564849853515625e-4f, r);
+  r = fmaf(y, -3.77489497744594108e-8f, r);
+  int neg, use_cos_poly;
+  if (want_cos) {
+    int j2 = j - 2;
+    neg = ((~j2) & 4) != 0;
+    use_cos_poly = (j2 & 2) != 0;
+  } else {
+    neg = (((j & 4) != 0) ^ (signbit(x) != 0));
+    use_cos_poly = (j & 2) != 0;
+  }
+  float z = r * r, v;
+  if (use_cos_poly) {
+    float p = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    p = fmaf(p, z, 4.166664568298827e-2f);
+    p = p * z;
+    p = p * z;
+    p = fmaf(z, -0.5f, p);
+    v = p + 1.0f;
+  } else {
+    float q = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    q = fmaf(q, z, -1.6666654611e-1f);
+    q = q * z;
+    v = fmaf(q, r, r);
+  }
+  return neg ? -v : v;
+}
+static float gsin(float x) { return sincos_core(x, 0); }
+static float gcos(float x) { return sincos_core(x, 1); }
+static float gacos(float x) {
+  float ax = fabsf(x);
+  float t = ax * (-0.02363318f) + 0.08132463f;
+  t = ax * t + (-0.2145988f);
+  t = ax * t + 1.5707964f;
+  return 1.5707964f - gsign(x) * (1.5707964f - sqrtf(1.0f - ax) * t);
+}
+static float gexp2(float y) {
+  y = gmin(y, 129.0f);
+  y = gmax(y, -126.99999f);
+  float ip = floorf(y);
+  float fp = y - ip;
+  float t2 = fp * fp;
+  float e = fmaf(t2, 0.00898934009049466391101f, 0.240153617044375388211f);
+  e = fmaf(t2, e, 1.0f);
+  float o = fmaf(t2, 0.00187757667519147912699f, 0.0558263180532956664775f);
+  o = fmaf(t2, o, 0.693153073200168932794f);
+  return ldexpf(1.0f, (int)ip) * fmaf(o, fp, e);
+}
+/* svotrace.comp:26-29 */
+static float glsl_rand(float cx, float cy) {
+  float s = gsin(cx * 12.9898f + cy * 78.233f);
+  float v = s * 43758.5453f;
+  return v - floorf(v);
+}
+
+/* ------------------------------------------------------------------ node decode */
+
+typedef struct {
+  int value;
+  int cp;
+  int leafMask;
+  uint32_t descriptor;
+} Node;
+
+/* :75-79 -- the pool is viewed as little-endian dwords, so byte p is pool[p];
+   reads past the uploaded bytes return 0 (the reference buffer is over-allocated
+   and zero-filled, Octree.java:63-67) */
+static inline int get_byte(const ctx_t *c, uint32_t p) { return p < c->len ? (int)c->pool[p] : 0; }
+
+static Node extract_node(const ctx_t *c, uint32_t p) { /* :88-101 */
+  Node n;
+  n.descriptor = p;
+  n.value = get_byte(c, p);
+  n.cp = (int)(((uint32_t)get_byte(c, p + 1) << 24) | ((uint32_t)get_byte(c, p + 2) << 16) |
+               ((uint32_t)get_byte(c, p + 3) << 8) | (uint32_t)get_byte(c, p + 4));
+  n.leafMask = (get_byte(c, p + 5) << 8) | get_byte(c, p + 6);
+  return n;
+}
+static Node extract_leaf(const ctx_t *c, uint32_t p) { /* :103-108 */
+  Node n = {get_byte(c, p), 0, 0, p};
+  n.leafMask = get_byte(c, p + 1) | (get_byte(c, p + 2) << 8);
+  return n;
+}
+static Node extract_non_surface_leaf(const ctx_t *c, uint32_t p) { /* :110-114 */
+  Node n = {get_byte(c, p), 0, 0, p};
+  return n;
+}
+static Node extract_subdividable_leaf(const ctx_t *c, uint32_t p) { /* :116-130 */
+  Node n = extract_node(c, p);
+  n.cp = 0;
+  return n;
+}
+/* :132-157 */
+static Node extract_child(const ctx_t *c, uint32_t parentPointer, uint32_t childPointer, uint32_t child, int leafMask,
+                          uint32_t *endPointer, uint32_t *rec_size) {
+  uint32_t i = 0;
+  uint32_t pointer = childPointer + parentPointer;
+  while (i < child) {
+    int localMask = (leafMask & (0x0003 << (i << 1))) >> (i << 1);
+    if (localMask == 0 || localMask == 2) pointer += NODE_SIZE;
+    else if (localMask == 1) pointer += LEAF_SIZE;
+    else pointer += NON_SURFACE_LEAF_SIZE;
+    i++;
+  }
+  *endPointer = pointer;
+  int localMask = (leafMask & (0x0003 << (child << 1))) >> (child << 1);
+  if (localMask == 0) { *rec_size = NODE_SIZE; return extract_node(c, pointer); }
+  if (localMask == 1) { *rec_size = LEAF_SIZE; return extract_leaf(c, pointer); }
+  if (localMask == 2) { *rec_size = NODE_SIZE; return extract_subdividable_leaf(c, pointer); }
+  *rec_size = NON_SURFACE_LEAF_SIZE;
+  return extract_non_surface_leaf(c, pointer);
+}
+
+/* ------------------------------------------------------------------ traversal */
+
+typedef struct {
+  uint32_t value, pointer, iter;
+  float t;
+  vec3 hitPos;
+  float scale;
+  vec3 debugColor;
+  vec3 normal;
+  vec3 voxelPos;
+  uint32_t depth;
+  int leafMask; /* not in the reference struct: raw leafMask field of the hit node, for hit records */
+} castResult;
+
+typedef struct {
+  Node node;
+  float tmax;
+} stackEntry;
+
+static inline int all_nan3(vec3 v) { return isnan(v.x) && isnan(v.y) && isnan(v.z); }
+
+/* :211-432.  `invdir` of the reference is unused and omitted. */
+static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, int maxDepth, int coneTrace) {
+  stackEntry octstack[MAX_SCALE + 1];
+  memset(octstack, 0, sizeof octstack);
+  res->debugColor = v3(0.3f, 0.3f, 0.6f);
+  Node parent = extract_node(c, 0);
+  uint32_t iter = 0;
+  uint64_t bytes = NODE_SIZE;
+  int is_nan_ray = all_nan3(origin) || all_nan3(dir);
+
+  if (fabsf(dir.x) < EPSILON) dir.x = EPSILON * gsign(dir.x);
+  if (fabsf(dir.y) < EPSILON) dir.y = EPSILON * gsign(dir.y);
+  if (fabsf(dir.z) < EPSILON) dir.z = EPSILON * gsign(dir.z);
+
+  float tx_coef = 1.0f / -fabsf(dir.x);
+  float ty_coef = 1.0f / -fabsf(dir.y);
+  float tz_coef = 1.0f / -fabsf(dir.z);
+
+  float tx_bias = tx_coef * origin.x;
+  float ty_bias = ty_coef * origin.y;
+  float tz_bias = tz_coef * origin.z;
+
+  uint32_t octant_mask = 0;
+  if (dir.x > 0.0f) { octant_mask ^= 1u; tx_bias = 3.0f * tx_coef - tx_bias; }
+  if (dir.y > 0.0f) { octant_mask ^= 2u; ty_bias = 3.0f * ty_coef - ty_bias; }
+  if (dir.z > 0.0f) { octant_mask ^= 4u; tz_bias = 3.0f * tz_coef - tz_bias; }
+
+  float t_min = gmax(gmax(2.0f * tx_coef - tx_bias, 2.0f * ty_coef - ty_bias), 2.0f * tz_coef - tz_bias);
+  float t_max = gmin(gmin(tx_coef - tx_bias, ty_coef - ty_bias), tz_coef - tz_bias);
+  t_min = gmax(t_min, 0.0f);
+  float h = t_max;
+
+  uint32_t idx = 0;
+  vec3 pos = v3(1.0f, 1.0f, 1.0f);
+  int scale = MAX_SCALE - 1;
+  float scale_exp2 = 0.5f;
+  int child_descriptor = 0;
+
+  if (1.5f * tx_coef - tx_bias > t_min) { idx ^= 1u; pos.x = 1.5f; }
+  if (1.5f * ty_coef - ty_bias > t_min) { idx ^= 2u; pos.y = 1.5f; }
+  if (1.5f * tz_coef - tz_bias > t_min) { idx ^= 4u; pos.z = 1.5f; }
+  uint32_t child_shift = 0;
+  int ok = 0, capped = 0;
+
+  while (scale < MAX_SCALE) {
+    iter++;
+    if (iter > MAX_RAYCAST_ITERATIONS) { capped = 1; break; }
+    if (child_descriptor == 0) child_descriptor = parent.cp;
+    if (t_min > 0.05f && coneTrace) maxDepth = 11;
+
+    float tx_corner = pos.x * tx_coef - tx_bias;
+    float ty_corner = pos.y * ty_coef - ty_bias;
+    float tz_corner = pos.z * tz_coef - tz_bias;
+    float tc_max = gmin(gmin(tx_corner, ty_corner), tz_corner);
+
+    child_shift = idx ^ octant_mask;
+    uint32_t rec;
+    Node child = extract_child(c, parent.descriptor, (uint32_t)child_descriptor, child_shift, parent.leafMask,
+                               &res->pointer, &rec);
+    bytes += rec;
+    if (child.value != 0 && t_min <= t_max) {
+      if (MAX_SCALE - scale == maxDepth) { ok = 1; break; }
+      float tv_max = gmin(t_max, tc_max);
+      float one_half = scale_exp2 * 0.5f;
+      float tx_center = one_half * tx_coef + tx_corner;
+      float ty_center = one_half * ty_coef + ty_corner;
+      float tz_center = one_half * tz_coef + tz_corner;
+      if (t_min <= tv_max) {
+        if (child.cp == 0) { ok = 1; break; }
+        if (tc_max < h) {
+          octstack[scale].node = parent;
+          octstack[scale].tmax = t_max;
+        }
+        h = tc_max;
+        parent = child;
+        idx = 0u;
+        --scale;
+        scale_exp2 = one_half;
+        if (tx_center > t_min) { idx ^= 1u; pos.x += scale_exp2; }
+        if (ty_center > t_min) { idx ^= 2u; pos.y += scale_exp2; }
+        if (tz_center > t_min) { idx ^= 4u; pos.z += scale_exp2; }
+        t_max = tv_max;
+        child_descriptor = 0;
+        continue;
+      }
+    }
+    /* ADVANCE */
+    uint32_t step_mask = 0u;
+    if (tx_corner <= tc_max) { step_mask ^= 1u; pos.x -= scale_exp2; }
+    if (ty_corner <= tc_max) { step_mask ^= 2u; pos.y -= scale_exp2; }
+    if (tz_corner <= tc_max) { step_mask ^= 4u; pos.z -= scale_exp2; }
+    t_min = tc_max;
+    idx ^= step_mask;
+    /* POP */
+    if ((idx & step_mask) != 0) {
+      uint32_t differing_bits = 0;
+      if (step_mask & 1u) differing_bits |= f2u(pos.x) ^ f2u(pos.x + scale_exp2);
+      if (step_mask & 2u) differing_bits |= f2u(pos.y) ^ f2u(pos.y + scale_exp2);
+      if (step_mask & 4u) differing_bits |= f2u(pos.z) ^ f2u(pos.z + scale_exp2);
+      scale = find_msb(differing_bits);
+      scale_exp2 = u2f(((uint32_t)scale - (uint32_t)MAX_SCALE + 127u) << 23u);
+      if (scale >= 0 && scale <= MAX_SCALE) { /* pin P6: the reference reads out of bounds here; value is dead */
+        parent = octstack[scale].node;
+        t_max = octstack[scale].tmax;
+      }
+      uint32_t sh = (uint32_t)scale & 31u;
+      uint32_t shx = f2u(pos.x) >> sh, shy = f2u(pos.y) >> sh, shz = f2u(pos.z) >> sh;
+      pos.x = u2f(shx << sh);
+      pos.y = u2f(shy << sh);
+      pos.z = u2f(shz << sh);
+      idx = (shx & 1u) | ((shy & 1u) << 1u) | ((shz & 1u) << 2u);
+      h = 0.0f;
+      child_descriptor = 0;
+    }
+  }
+
+  if (is_nan_ray) {
+    c->st->nan_rays++;
+  } else {
+    c->st->rays++;
+    c->st->iterations += iter > MAX_RAYCAST_ITERATIONS ? MAX_RAYCAST_ITERATIONS : iter;
+    c->st->alg_bytes += bytes;
+  }
+
+  /* pin P7: fields the reference leaves unwritten on its early returns behave as if
+     assigned from the cast's own state */
+  res->iter = iter;
+  res->t = t_min;
+  res->scale = scale_exp2;
+  if (capped) return 0; /* :263-266 */
+  if (!ok) {            /* :371-377 */
+    res->debugColor = v3(0.01f * (float)iter, 0.01f * (float)iter, 0.01f * (float)iter);
+    return 0;
+  }
+
+  vec3 norm = v3(0.0f, 0.0f, 0.0f);
+  uint32_t rec;
+  Node target = extract_child(c, parent.descriptor, (uint32_t)child_descriptor, child_shift, parent.leafMask,
+                              &res->pointer, &rec);
+  if (target.leafMask != 0) {
+    int raw = target.leafMask;
+    float normX = (float)((raw % 10) - 5);
+    float normY = (float)((((raw % 100) - (raw % 10)) / 10) - 5);
+    float normZ = (float)(((raw - (raw % 100)) / 100) - 5);
+    norm = gnormalize(v3(normX, normY, normZ));
+  }
+  res->t = t_min;
+  res->value = (uint32_t)target.value;
+  res->leafMask = target.leafMask;
+  res->iter = iter;
+  res->normal = norm;
+  res->scale = scale_exp2;
+  res->depth = (uint32_t)(MAX_SCALE - scale);
+  /* res.hitPos = origin + t_min * dir + norm * scale_exp2*2  (value never read) */
+  res->hitPos = vadd(vadd(origin, vscale(dir, t_min)), vscale(vscale(norm, scale_exp2), 2.0f));
+
+  vec3 vp = pos;
+  if (dir.x > 0) vp.x = 3.0f - vp.x - scale_exp2;
+  if (dir.y > 0) vp.y = 3.0f - vp.y - scale_exp2;
+  if (dir.z > 0) vp.z = 3.0f - vp.z - scale_exp2;
+  /* vp += norm * scale_exp2 * 2 * 1.74  -- left-associative, float throughout */
+  vp.x += ((norm.x * scale_exp2) * 2.0f) * 1.74f;
+  vp.y += ((norm.y * scale_exp2) * 2.0f) * 1.74f;
+  vp.z += ((norm.z * scale_exp2) * 2.0f) * 1.74f;
+  res->voxelPos = vp;
+  res->debugColor = v3(0.005f * (float)iter, 0.005f * (float)iter, 0.005f * (float)iter);
+  return scale < MAX_SCALE && t_min <= t_max;
+}
+
+/* ------------------------------------------------------------------ shading */
+
+static void record_hit(svo_hit *hit, const castResult *res, int intersect) {
+  if (!hit) return;
+  if (intersect) {
+    hit->pointer = res->pointer;
+    hit->raw_normal = (uint16_t)res->leafMask;
+    hit->value = (uint8_t)res->value;
+    hit->level = (uint8_t)res->depth;
+    hit->iter = res->iter;
+    hit->t = res->t;
+  } else {
+    hit->pointer = 0;
+    hit->raw_normal = 0;
+    hit->value = 0;
+    hit->level = 0;
+    hit->iter = res->iter;
+    hit->t = 0.0f;
+  }
+}
+
+/* :435-646 */
+static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, vec3 origin, vec3 dir, float seed0,
+                  float seed1, float seed2, float *depth, svo_hit *hit) {
+  castResult res;
+  memset(&res, 0, sizeof res);
+  res.t = 2.0f;
+  origin = vadd(origin, vscale(dir, beamDist));
+  int intersect = 1;
+  vec3 accum = v3(0, 0, 0), mask = v3(1, 1, 1), normal;
+  int mode = prm->render_mode;
+  if (mode == 0) {
+    for (int i = 0; i < prm->bounces; i++) {
+      int coneTrace = i != 0;
+      intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, coneTrace);
+      if (i == 0) record_hit(hit, &res, intersect);
+      if (!intersect && i == 0) {
+        vec3 sky = v3(0.6725f, 0.8784f, 1.0f);
+        accum = vadd(accum, v3(sky.x - dir.y * 0.4f, sky.y - dir.y * 0.4f, sky.z - dir.y * 0.25f));
+        break;
+      }
+      normal = res.normal;
+      vec3 hitpoint = res.voxelPos;
+      float r = glsl_rand(seed0 + glsl_rand(seed0, seed2 * 0.1f), seed1 + glsl_rand(seed1, seed2 * 0.02f));
+      float rand1 = (2.0f * PI_F) * r;
+      vec3 w = normal;
+      vec3 axis = fabsf(w.x) > 0.1f ? v3(0, 1, 0) : v3(1, 0, 0);
+      vec3 u = gnormalize(gcross(axis, w));
+      vec3 v = gcross(w, u);
+      vec3 newdir;
+      if ((prm->mirror_mask >> (res.value & 31u)) & 1u) {
+        /* dormant :503  newdir = dir - 2 * dot(dir, normal) * normal */
+        float k = 2.0f * dot3(dir, normal);
+        newdir = v3(dir.x - k * normal.x, dir.y - k * normal.y, dir.z - k * normal.z);
+      } else {
+        float cs = gcos(rand1), sn = gsin(rand1), om = 1.0f - r;
+        newdir = gnormalize(vadd(vadd(vscale(u, cs), vscale(v, sn)), vscale(w, om)));
+      }
+      origin = hitpoint;
+      dir = newdir;
+      vec3 matcolor = v3(hitpoint.x - 1.0f, hitpoint.y - 1.0f, hitpoint.z - 1.0f);
+      if (res.value == 1) matcolor = v3(0.84f, 0.86f, 0.78f);
+      if (res.value == 2) matcolor = v3(0.57f, 0.5f, 0.31f);
+      if (res.value == 3) matcolor = v3(0.37f, 0.43f, 0.27f);
+      if (intersect) {
+        *depth = res.t;
+        accum = vadd(accum, vmul(mask, v3(0, 0, 0)));
+        mask = vmul(mask, matcolor);
+        mask = vscale(mask, dot3(newdir, normal));
+      } else {
+        vec3 sun_dir = gnormalize(v3(1.0f, 1.0f, 1.0f));
+        float diff = gacos(dot3(dir, sun_dir));
+        if (diff < 0.4f) accum = vadd(accum, vscale(mask, 7.0f));
+        accum = vadd(accum, vscale(mask, 1.0f));
+        *depth = 0.0f;
+        break;
+      }
+    }
+    return accum;
+  } else if (mode == 1) {
+    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0);
+    record_hit(hit, &res, intersect);
+    *depth = intersect ? res.t : 0.0f;
+    return res.debugColor;
+  } else if (mode == 2) {
+    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0);
+    record_hit(hit, &res, intersect);
+    if (intersect) {
+      *depth = res.t;
+      vec3 matcolor = v3(0, 0, 0); /* pin P8 */
+      if (res.value == 1) matcolor = v3(0.84f, 0.86f, 0.78f);
+      if (res.value == 2) matcolor = v3(0.57f, 0.5f, 0.31f);
+      if (res.value == 3) matcolor = v3(0.37f, 0.43f, 0.27f);
+      vec3 sun_dir = gnormalize(v3(0.5f, 0.5f, 0.5f));
+      float ph = dot3(res.normal, sun_dir) * 0.1f;
+      if (res.depth >= 10) {
+        matcolor = v3(matcolor.x + ph, matcolor.y + ph, matcolor.z + ph);
+      } else {
+        float k = dot3(v3(0, 1.0f, 0), sun_dir) * 0.1f;
+        matcolor = v3(matcolor.x + k, matcolor.y + k, matcolor.z + k);
+      }
+      float trueDist = res.t + beamDist;
+      /* exp(-0.5*d*K) = exp2(d * (-0.5*K*log2e)), SURVEY Appendix C */
+      float lambdag = gexp2(trueDist * (-0.5f * 2.0f * 1.44269504f));
+      float lambdab = gexp2(trueDist * (-0.5f * 4.0f * 1.44269504f));
+      float lambdar = gexp2(trueDist * (-0.5f * 1.0f * 1.44269504f));
+      matcolor.x = lambdar * matcolor.x + (1.0f - lambdar) * 1.0f;
+      matcolor.y = lambdag * matcolor.y + (1.0f - lambdag) * 1.0f;
+      matcolor.z = lambdab * matcolor.z + (1.0f - lambdab) * 1.0f;
+      /* shadow ray; `res` is reused exactly as in the reference (:607) */
+      vec3 so = res.voxelPos;
+      int sh = intersect_octree(c, so, sun_dir, &res, MAX_DEPTH, 0);
+      if (sh && res.t > res.scale * SQRT3_F) {
+        matcolor = v3(matcolor.x - 0.2f, matcolor.y - 0.2f, matcolor.z - 0.2f);
+      } else if (res.iter > 260) {
+        float pen = (0.05f * (float)res.iter) / 100.0f;
+        matcolor = v3(matcolor.x - pen, matcolor.y - pen, matcolor.z - pen);
+      }
+      return matcolor;
+    } else {
+      *depth = 0.0f;
+      return v3(0.6725f - dir.y * 0.4f, 0.8784f - dir.y * 0.4f, 1.0f - dir.y * 0.25f);
+    }
+  } else if (mode == 3) {
+    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0);
+    record_hit(hit, &res, intersect);
+    if (intersect) {
+      *depth = res.t;
+      return v3(res.normal.x * 0.5f + 0.5f, res.normal.y * 0.5f + 0.5f, res.normal.z * 0.5f + 0.5f);
+    }
+    *depth = 0.0f;
+    return v3(0, 0, 0);
+  }
+  /* mode 4 (:643-645) returns the unset res.voxelPos; modes >= 5 fall off the end: zero (pin P8) */
+  if (hit) memset(hit, 0, sizeof *hit);
+  return v3(0, 0, 0);
+}
+
+/* imageStore to rgba8 (pin P9): clamp, round-half-even; NaN -> 255 */
+static uint8_t unorm8(float x) {
+  if (isnan(x)) return 255;
+  if (x <= 0.0f) return 0;
+  if (x >= 1.0f) return 255;
+  return (uint8_t)rintf(x * 255.0f);
+}
+
+/*
+ * Render pixels (x, y) with y in [y0, y1), x in [0, width), taking every xstep-th /
+ * ystep-th pixel (others are left untouched).  Output layouts match the reference's
+ * GL images: rgba8 row-major, row 0 = p.y = 0 (svotrace.comp:662-664, 726-727).
+ * Any of rgba / depth / hits may be NULL.
+ */
+int svo_oracle_render(const uint8_t *pool, uint64_t pool_len, const svo_oracle_params *prm, int y0, int y1, int xstep,
+                      int ystep, uint8_t *rgba, float *depth_out, svo_hit *hits, svo_oracle_stats *stats) {
+  svo_oracle_stats local;
+  memset(&local, 0, sizeof local);
+  ctx_t c = {pool, pool_len, stats ? stats : &local, 0};
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (pool_len < NODE_SIZE || prm->width <= 0 || prm->height <= 0) return 1;
+  if (xstep < 1) xstep = 1;
+  if (ystep < 1) ystep = 1;
+  int W = prm->width, Hh = prm->height;
+  vec3 camPos = v3(prm->cam[0], prm->cam[1], prm->cam[2]);
+  vec3 l1 = v3(prm->cam[3], prm->cam[4], prm->cam[5]), l2 = v3(prm->cam[6], prm->cam[7], prm->cam[8]);
+  vec3 r1 = v3(prm->cam[9], prm->cam[10], prm->cam[11]), r2 = v3(prm->cam[12], prm->cam[13], prm->cam[14]);
+  uint32_t dword0 = (uint32_t)get_byte(&c, 0) | ((uint32_t)get_byte(&c, 1) << 8) | ((uint32_t)get_byte(&c, 2) << 16) |
+                    ((uint32_t)get_byte(&c, 3) << 24);
+  int spp = prm->spp < 1 ? 1 : prm->spp;
+  for (int py = y0; py < y1 && py < Hh; py += ystep) {
+    for (int px = 0; px < W; px += xstep) {
+      float p_x = ((float)px + 0.5f) / (float)W;
+      float p_y = ((float)py + 0.5f) / (float)Hh;
+      vec3 a = v3(gmix(l1.x, l2.x, p_y), gmix(l1.y, l2.y, p_y), gmix(l1.z, l2.z, p_y));
+      vec3 b = v3(gmix(r1.x, r2.x, p_y), gmix(r1.y, r2.y, p_y), gmix(r1.z, r2.z, p_y));
+      vec3 dir = v3(gmix(a.x, b.x, p_x), gmix(a.y, b.y, p_x), gmix(a.z, b.z, p_x));
+      vec3 normdir = gnormalize(dir);
+      /* `float depth = -1.0f` at :672 is lost: a mode-0 primary miss stores 0.0 (pin P7) */
+      float depth = 0.0f;
+      vec3 fin = v3(0, 0, 0);
+      svo_hit hit;
+      memset(&hit, 0, sizeof hit);
+      for (int s = 0; s < spp; s++) {
+        float d_s = 0.0f;
+        vec3 col = trace(&c, prm, 0.0f, camPos, normdir, (float)px, (float)py, (float)(prm->frame_number + s), &d_s,
+                         s == 0 ? &hit : NULL);
+        if (s == 0) depth = d_s;
+        fin = vadd(fin, col);
+      }
+      if (spp > 1) fin = vscale(fin, 1.0f / (float)spp);
+      vec3 debugColor = v3(1, 1, 1);
+      if (dword0 == 0) debugColor = v3(1.0f, 0.0f, 0.0f);
+      if (px < 10 && py < 10) fin = debugColor;
+      size_t o = (size_t)py * (size_t)W + (size_t)px;
+      if (rgba) {
+        rgba[o * 4 + 0] = unorm8(fin.x);
+        rgba[o * 4 + 1] = unorm8(fin.y);
+        rgba[o * 4 + 2] = unorm8(fin.z);
+        rgba[o * 4 + 3] = 255;
+      }
+      if (depth_out) depth_out[o] = depth;
+      if (hits) hits[o] = hit;
+      c.st->pixels++;
+    }
+  }
+  return 0;
+}
+
+/* exported for tests of the pinned transcendentals */
+float svo_oracle_sin(float x) { return gsin(x); }
+float svo_oracle_cos(float x) { return gcos(x); }
+float svo_oracle_acos(float x) { return gacos(x); }
+float svo_oracle_exp2(float x) { return gexp2(x); }
+float svo_oracle_rand(float a, float b) { return glsl_rand(a, b); }

@@ -1,0 +1,111 @@
+"""ctypes binding of the procedural scene generator (scene/svo_scene.c)."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "scene", "libsvoscene.so")
+_lib = None
+
+
+class SceneStats(ctypes.Structure):
+    _fields_ = [
+        ("bytes", ctypes.c_uint64),
+        ("interior", ctypes.c_uint64),
+        ("surface_leaf", ctypes.c_uint64),
+        ("nonsurface_leaf", ctypes.c_uint64),
+        ("subdiv_leaf", ctypes.c_uint64),
+        ("depth", ctypes.c_int32),
+        ("hmin", ctypes.c_int32),
+        ("hmax", ctypes.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(_LIB_PATH)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.svo_scene_build.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(u8p),
+                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(SceneStats)]
+        L.svo_scene_build.restype = ctypes.c_int
+        L.svo_scene_free.argtypes = [u8p]
+        L.svo_scene_free.restype = None
+        L.svo_scene_height.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.svo_scene_height.restype = ctypes.c_int
+        L.svo_pool_validate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SceneStats),
+                                        ctypes.POINTER(ctypes.c_int)]
+        L.svo_pool_validate.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def build_scene(n, seed=1, amp=8):
+    """Build an n^3 procedural terrain SVO. Returns (pool: np.uint8[len], stats dict)."""
+    L = lib()
+    p = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_uint64()
+    st = SceneStats()
+    rc = L.svo_scene_build(int(n), int(seed), int(amp), ctypes.byref(p), ctypes.byref(ln), ctypes.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"svo_scene_build({n}) failed rc={rc} (3 = pool would exceed 2^31 bytes: {ln.value})")
+    try:
+        pool = np.ctypeslib.as_array(p, shape=(ln.value,)).copy()
+    finally:
+        L.svo_scene_free(p)
+    return pool, st.as_dict()
+
+
+def height(n, x, z, seed=1, amp=8):
+    return lib().svo_scene_height(int(n), int(seed), int(amp), int(x), int(z))
+
+
+def validate_pool(pool):
+    """Walk the pool; returns (rc, stats dict, max_depth). rc == 0 means consistent."""
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    st = SceneStats()
+    md = ctypes.c_int()
+    rc = lib().svo_pool_validate(pool.ctypes.data, pool.size, ctypes.byref(st), ctypes.byref(md))
+    return rc, st.as_dict(), md.value
+
+
+def embed_deep(pool, k):
+    """make a (depth + k)-deep pool from a shallow one by chaining k
+    all-interior nodes (child 0 interior, children 1..7 empty tag-2 leaves) above it.
+    The scene then occupies [1, 1 + 2^-k]^3."""
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    if k == 0:
+        return pool.copy()
+    mask_chain = 0
+    for n in range(1, 8):
+        mask_chain |= 2 << (2 * n)
+    out = bytearray()
+    # chain node i sits at offset i*56 (node + its 8 children: 8*7 bytes, child 0 is the next chain node)
+    # layout: [n0][c0_0..c0_7][c1_0..c1_7]... where c(i)_0 is chain node i+1
+    offs = [0]
+    out += bytes([1, 0, 0, 0, 0, 0, 0])
+    for i in range(k):
+        block = len(out)
+        for n in range(8):
+            out += bytes([1 if n == 0 else 0, 0, 0, 0, 0, 0, 0])
+        cp = block - offs[i]
+        out[offs[i] + 1:offs[i] + 5] = int(cp).to_bytes(4, "big", signed=True)
+        if i < k - 1 or True:
+            out[offs[i] + 5:offs[i] + 7] = int(mask_chain).to_bytes(2, "big")
+        offs.append(block)
+    last = offs[k]
+    # last chain node adopts the shallow root's leafMask and points at its child block, appended verbatim
+    root_cp = int.from_bytes(bytes(pool[1:5]), "big", signed=True)
+    body = bytes(pool[root_cp:])
+    cp = len(out) - last
+    out[last] = int(pool[0])
+    out[last + 1:last + 5] = int(cp).to_bytes(4, "big", signed=True)
+    out[last + 5:last + 7] = bytes(pool[5:7])
+    out += body
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy()

@@ -1,0 +1,514 @@
+/*
+ * svo_scene.c -- deterministic, integer-only procedural SVO scene generator.
+ *
+ * Produces a sparse-voxel-octree byte pool in EXACTLY the layout the reference's
+ * host code produces and its shader consumes:
+ *   interior   (tag 0) 7 B : value u8 | child pointer i32 BE, relative to this node | leafMask u16 BE
+ *   surface    (tag 1) 3 B : value u8 | packed normal u16 LE
+ *   subdivid.  (tag 2) 7 B : value u8 | 6 zero bytes
+ *   nonsurface (tag 3) 1 B : value u8
+ *   (encoders: reference Octree.java:119-176; tag bits: Octree.java:589-602)
+ * A parent's 8 children are contiguous, order n = x + 2y + 4z (Octree.java:42-51).
+ *
+ * The tree-construction RULES follow the reference builder (own code, not a copy):
+ *   - classification / node-type decisions      Octree.java:527-599 (constructInnerOctree)
+ *   - surface normal = sum of offsets to empty in-chunk 26-neighbours, /2 + 5 per axis,
+ *     packed nx + 10 ny + 100 nz                Octree.java:620-649 (genSurfaceNormal)
+ *   - "big node exposed" looks only at the 27 corner-region voxels, in-chunk
+ *                                               Octree.java:651-670 (checkBigNodeExposed)
+ *   - pool prefix = root + all-interior levels down to 1024^3 chunks, then per chunk
+ *     8 interior 512^3 nodes followed by their sub-octrees
+ *                                               Octree.java:232-353, 481-502
+ *   - voxel rule: solid iff y <= h(x,z); top 5 layers take the surface material,
+ *     below that material 1                     chunkgen-heightmap.comp:16-28
+ * What is NOT the reference's: the height field itself (the reference reads PNG
+ * height/material maps that are not shipped).  Here h(x,z) is fixed-point value-noise
+ * fBm from a 32-bit integer hash, so every language twin produces the same bytes, and
+ * the tree is built top-down from a min/max pyramid of h -- no dense voxel grid
+ * (8192^3 dense would be 512 GiB).
+ *
+ * Build: gcc -O2 -fopenmp -shared -fPIC (see __graft_entry__.build()).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NODE_SIZE 7
+#define LEAF_SIZE 3
+#define NS_LEAF_SIZE 1
+#define TASK_SIZE 512   /* OctreeThread.java:20-23 builds 512^3 sub-octrees */
+#define CHUNK_SIZE 1024 /* Octree.java:39 */
+
+typedef struct {
+  uint64_t bytes;
+  uint64_t interior, surface_leaf, nonsurface_leaf, subdiv_leaf;
+  int32_t depth; /* log2(N) */
+  int32_t hmin, hmax;
+} svo_scene_stats;
+
+typedef struct {
+  uint8_t *d;
+  size_t len, cap;
+} buf_t;
+
+typedef struct {
+  int N, chunk, nlev;
+  uint32_t seed;
+  uint16_t *h;     /* N*N heights, index z*N + x */
+  uint16_t **pmin; /* pyramid: level l covers cells of size 8<<l */
+  uint16_t **pmax;
+} scene_t;
+
+typedef struct {
+  uint64_t interior, surface_leaf, nonsurface_leaf, subdiv_leaf;
+} counts_t;
+
+/* ---------------------------------------------------------------- height field */
+
+static inline uint32_t mix32(uint32_t a) {
+  a ^= a >> 16; a *= 0x7feb352dU;
+  a ^= a >> 15; a *= 0x846ca68bU;
+  a ^= a >> 16;
+  return a;
+}
+static inline int64_t lattice16(uint32_t ix, uint32_t iz, uint32_t seed, uint32_t oct) {
+  return (int64_t)(mix32(ix * 0x9E3779B1U ^ mix32(iz * 0x85EBCA77U ^ mix32(seed + oct * 0x27d4eb2fU))) & 0xFFFFU);
+}
+/* smooth value noise in [0,65535], all integer */
+static int64_t noise16(int x, int z, int cell, uint32_t seed, uint32_t oct) {
+  int ix = x / cell, iz = z / cell;
+  int64_t tx = ((int64_t)(x - ix * cell) << 16) / cell;
+  int64_t tz = ((int64_t)(z - iz * cell) << 16) / cell;
+  int64_t sx = (((tx * tx) >> 16) * (3 * 65536 - 2 * tx)) >> 16;
+  int64_t sz = (((tz * tz) >> 16) * (3 * 65536 - 2 * tz)) >> 16;
+  int64_t v00 = lattice16((uint32_t)ix, (uint32_t)iz, seed, oct);
+  int64_t v10 = lattice16((uint32_t)ix + 1, (uint32_t)iz, seed, oct);
+  int64_t v01 = lattice16((uint32_t)ix, (uint32_t)iz + 1, seed, oct);
+  int64_t v11 = lattice16((uint32_t)ix + 1, (uint32_t)iz + 1, seed, oct);
+  int64_t a = v00 + (((v10 - v00) * sx) >> 16);
+  int64_t b = v01 + (((v11 - v01) * sx) >> 16);
+  return a + (((b - a) * sz) >> 16);
+}
+
+/* h(x,z) in [0,N): base 0.30 N plus 4 octaves with cell N/4, N/16, N/64, N/256 and
+   peak-to-peak amplitude (amp_num/16) * cell.  Scale-free in N. */
+int svo_scene_height(int N, uint32_t seed, int amp_num, int x, int z) {
+  int64_t h = (int64_t)N * 30 / 100;
+  int cell = N / 4;
+  for (uint32_t o = 0; o < 4 && cell >= 4; o++, cell /= 4) {
+    int64_t amp = (int64_t)cell * amp_num / 16;
+    h += (amp * (noise16(x, z, cell, seed, o) - 32768)) >> 16;
+  }
+  if (h < 0) h = 0;
+  if (h > N - 1) h = N - 1;
+  return (int)h;
+}
+
+static inline uint8_t band_material(const scene_t *s, int x, int z) {
+  return (uint8_t)(2 + (mix32((uint32_t)(x >> 5) * 0x9E3779B1U ^ mix32((uint32_t)(z >> 5) + s->seed * 0x61C88647U)) & 1U));
+}
+static inline int H(const scene_t *s, int x, int z) { return s->h[(size_t)z * s->N + x]; }
+/* voxel rule of chunkgen-heightmap.comp:16-28 */
+static inline uint8_t voxel(const scene_t *s, int x, int y, int z) {
+  int h = H(s, x, z);
+  if (y > h) return 0;
+  if (h - y <= 4) return band_material(s, x, z);
+  return 1;
+}
+
+/* ---------------------------------------------------------------- byte pool */
+
+static void buf_reserve(buf_t *b, size_t extra) {
+  if (b->len + extra <= b->cap) return;
+  size_t nc = b->cap ? b->cap * 2 : 4096;
+  while (nc < b->len + extra) nc *= 2;
+  b->d = (uint8_t *)realloc(b->d, nc);
+  if (!b->d) { fprintf(stderr, "svo_scene: out of memory\n"); abort(); }
+  b->cap = nc;
+}
+static size_t put_node7(buf_t *b, uint8_t val) {
+  buf_reserve(b, NODE_SIZE);
+  size_t p = b->len;
+  b->d[p] = val;
+  memset(b->d + p + 1, 0, 6);
+  b->len += NODE_SIZE;
+  return p;
+}
+static size_t put_surface_leaf(buf_t *b, uint8_t val, uint16_t normal) {
+  buf_reserve(b, LEAF_SIZE);
+  size_t p = b->len;
+  b->d[p] = val;
+  b->d[p + 1] = (uint8_t)(normal & 0xff); /* little-endian, Octree.java:150-151 */
+  b->d[p + 2] = (uint8_t)(normal >> 8);
+  b->len += LEAF_SIZE;
+  return p;
+}
+static size_t put_ns_leaf(buf_t *b, uint8_t val) {
+  buf_reserve(b, NS_LEAF_SIZE);
+  size_t p = b->len;
+  b->d[p] = val;
+  b->len += 1;
+  return p;
+}
+static void set_cp(uint8_t *d, size_t parent, int64_t rel) { /* int32 big-endian, Octree.java:162-164 */
+  uint32_t u = (uint32_t)(int32_t)rel;
+  d[parent + 1] = (uint8_t)(u >> 24);
+  d[parent + 2] = (uint8_t)(u >> 16);
+  d[parent + 3] = (uint8_t)(u >> 8);
+  d[parent + 4] = (uint8_t)u;
+}
+static void set_mask(uint8_t *d, size_t parent, uint16_t m) { /* u16 big-endian, Octree.java:170-172 */
+  d[parent + 5] = (uint8_t)(m >> 8);
+  d[parent + 6] = (uint8_t)m;
+}
+
+/* ---------------------------------------------------------------- classification */
+
+enum { K_EMPTY = 0, K_SOLID = 1, K_MIXED = 2 };
+
+static inline int in_chunk(const scene_t *s, int g, int c) {
+  int o = (c / s->chunk) * s->chunk;
+  return g >= o && g < o + s->chunk;
+}
+
+/* classify region [cx,cx+cs) x [cy,cy+cs) x [cz,cz+cs); value per Octree.java:528-555 */
+static int classify(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *value) {
+  if (cs >= 8) {
+    int l = 0;
+    while ((8 << l) < cs) l++;
+    int w = s->N / cs;
+    size_t pi = (size_t)(cz / cs) * w + (cx / cs);
+    int mn = s->pmin[l][pi], mx = s->pmax[l][pi];
+    if (mx < cy) { *value = 0; return K_EMPTY; }
+    if (cy + cs - 1 <= mn - 5) { *value = 1; return K_SOLID; }
+    /* mixed (an all-solid region of edge >= 6 touching the 5-layer
+       material band always also contains material 1) */
+    uint8_t v0 = voxel(s, cx, cy, cz);
+    if (v0) { *value = v0; return K_MIXED; }
+    /* first non-zero sample in the reference's z, y, x scan order: solid voxels of a
+       column form a prefix in y, so the first one is found on the y = cy plane */
+    for (int z = cz; z < cz + cs; z++) {
+      const uint16_t *row = s->h + (size_t)z * s->N;
+      for (int x = cx; x < cx + cs; x++)
+        if (row[x] >= cy) { *value = voxel(s, x, cy, z); return K_MIXED; }
+    }
+    *value = 0; /* unreachable: mx >= cy */
+    return K_EMPTY;
+  }
+  uint8_t first = voxel(s, cx, cy, cz), val = first;
+  if (cs == 1) { *value = first; return first ? K_SOLID : K_EMPTY; }
+  for (int z = cz; z < cz + cs; z++)
+    for (int y = cy; y < cy + cs; y++)
+      for (int x = cx; x < cx + cs; x++) {
+        uint8_t smp = voxel(s, x, y, z);
+        if (smp) val = smp;
+        if (smp != first) {
+          if (first == 0) first = smp;
+          *value = first;
+          return K_MIXED;
+        }
+      }
+  *value = val;
+  return val ? K_SOLID : K_EMPTY;
+}
+
+/* Octree.java:620-649 */
+static int surface_normal(const scene_t *s, int cx, int cy, int cz, uint16_t *packed) {
+  int exposed = 0, nx = 0, ny = 0, nz = 0;
+  for (int i = cx - 1; i <= cx + 1; i++) {
+    if (i < 0 || i >= s->N || !in_chunk(s, i, cx)) continue;
+    for (int k = cz - 1; k <= cz + 1; k++) {
+      if (k < 0 || k >= s->N || !in_chunk(s, k, cz)) continue;
+      int h = H(s, i, k);
+      for (int j = cy - 1; j <= cy + 1; j++) {
+        if (j < 0 || j >= s->N || !in_chunk(s, j, cy)) continue;
+        if (j > h) { exposed = 1; nx += i - cx; ny += j - cy; nz += k - cz; }
+      }
+    }
+  }
+  nx = nx / 2 + 5; ny = ny / 2 + 5; nz = nz / 2 + 5; /* C and Java both truncate toward zero */
+  *packed = (uint16_t)(nx + ny * 10 + nz * 100);
+  return exposed;
+}
+
+/* Octree.java:651-670: only coordinates {c-1, c+cs, c+cs+1} on every axis are looked at */
+static int big_node_exposed(const scene_t *s, int cx, int cy, int cz, int cs) {
+  int ax[3][3] = {{cx - 1, cx + cs, cx + cs + 1}, {cy - 1, cy + cs, cy + cs + 1}, {cz - 1, cz + cs, cz + cs + 1}};
+  int c0[3] = {cx, cy, cz};
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++)
+      for (int c = 0; c < 3; c++) {
+        int x = ax[0][a], y = ax[1][b], z = ax[2][c];
+        if (x < 0 || x >= s->N || !in_chunk(s, x, c0[0])) continue;
+        if (y < 0 || y >= s->N || !in_chunk(s, y, c0[1])) continue;
+        if (z < 0 || z >= s->N || !in_chunk(s, z, c0[2])) continue;
+        if (voxel(s, x, y, z) == 0) return 1;
+      }
+  return 0;
+}
+
+enum { T_INTERIOR = 0, T_SURFACE = 1, T_SUBDIV = 2, T_NONSURFACE = 3 };
+
+/* restates the decision structure of Octree.java:511-608 for the node at parent_off */
+static void build_children(const scene_t *s, buf_t *b, counts_t *cnt, size_t parent_off, int px, int py, int pz,
+                           int size) {
+  int cs = size / 2;
+  if (cs == 0) return;
+  size_t child_off[8];
+  uint8_t child_val[8];
+  int child_type[8];
+  uint16_t mask = 0;
+  for (int n = 0; n < 8; n++) {
+    int cx = px + (n & 1) * cs, cy = py + ((n >> 1) & 1) * cs, cz = pz + ((n >> 2) & 1) * cs;
+    uint8_t val;
+    int kind = classify(s, cx, cy, cz, cs, &val);
+    int type;
+    if (kind == K_SOLID) {
+      if (cs == 1) {
+        uint16_t nrm;
+        if (surface_normal(s, cx, cy, cz, &nrm)) {
+          child_off[n] = put_surface_leaf(b, val, nrm); type = T_SURFACE; cnt->surface_leaf++;
+        } else {
+          child_off[n] = put_ns_leaf(b, val); type = T_NONSURFACE; cnt->nonsurface_leaf++;
+        }
+      } else if (big_node_exposed(s, cx, cy, cz, cs)) {
+        child_off[n] = put_node7(b, val); type = T_INTERIOR; cnt->interior++;
+      } else {
+        child_off[n] = put_node7(b, val); type = T_SUBDIV; cnt->subdiv_leaf++;
+      }
+    } else if (kind == K_EMPTY) {
+      if (cs == 1) {
+        child_off[n] = put_ns_leaf(b, val); type = T_NONSURFACE; cnt->nonsurface_leaf++;
+      } else {
+        child_off[n] = put_node7(b, val); type = T_SUBDIV; cnt->subdiv_leaf++;
+      }
+    } else {
+      child_off[n] = put_node7(b, val); type = T_INTERIOR; cnt->interior++;
+    }
+    child_val[n] = val;
+    child_type[n] = type;
+    mask |= (uint16_t)(type << (n << 1));
+  }
+  set_cp(b->d, parent_off, (int64_t)child_off[0] - (int64_t)parent_off);
+  set_mask(b->d, parent_off, mask);
+  for (int n = 0; n < 8; n++) {
+    if (child_val[n] != 0 && child_type[n] == T_INTERIOR) {
+      int cx = px + (n & 1) * cs, cy = py + ((n >> 1) & 1) * cs, cz = pz + ((n >> 2) & 1) * cs;
+      build_children(s, b, cnt, child_off[n], cx, cy, cz, cs);
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- top of the tree */
+
+typedef struct {
+  size_t node_off;
+  int x, y, z;
+} chunk_t;
+
+/* Octree.java:481-502 (fillEmptyChildren): all-interior value-1 levels down to the chunks */
+static void fill_top(buf_t *b, counts_t *cnt, size_t parent, int levels, int x, int y, int z, chunk_t *chunks,
+                     size_t *nchunks) {
+  if (levels == 0) {
+    chunks[*nchunks].node_off = parent;
+    chunks[*nchunks].x = x; chunks[*nchunks].y = y; chunks[*nchunks].z = z;
+    (*nchunks)++;
+    return;
+  }
+  int cs = CHUNK_SIZE << (levels - 1);
+  size_t ch[8];
+  for (int i = 0; i < 8; i++) { ch[i] = put_node7(b, 1); cnt->interior++; }
+  for (int i = 0; i < 8; i++)
+    fill_top(b, cnt, ch[i], levels - 1, x + (i & 1) * cs, y + ((i >> 1) & 1) * cs, z + ((i >> 2) & 1) * cs, chunks,
+             nchunks);
+  set_cp(b->d, parent, (int64_t)ch[0] - (int64_t)parent);
+}
+
+static void free_scene(scene_t *s) {
+  if (s->pmin) for (int l = 0; l < s->nlev; l++) { free(s->pmin[l]); free(s->pmax[l]); }
+  free(s->pmin); free(s->pmax); free(s->h);
+}
+
+/*
+ * Build the scene. N must be a power of two in [8, 8192].  amp_num/16 = octave
+ * peak-to-peak amplitude in units of the octave's cell size (8 = default terrain).
+ * Returns 0 on success; *out_pool is malloc'ed (free with svo_scene_free).
+ */
+int svo_scene_build(int N, uint32_t seed, int amp_num, uint8_t **out_pool, uint64_t *out_len, svo_scene_stats *st) {
+  if (N < 8 || N > 8192 || (N & (N - 1))) return 1;
+  scene_t s;
+  memset(&s, 0, sizeof s);
+  s.N = N; s.seed = seed; s.chunk = N < CHUNK_SIZE ? N : CHUNK_SIZE;
+  s.h = (uint16_t *)malloc((size_t)N * N * sizeof(uint16_t));
+  if (!s.h) return 2;
+#pragma omp parallel for schedule(static)
+  for (int z = 0; z < N; z++)
+    for (int x = 0; x < N; x++) s.h[(size_t)z * N + x] = (uint16_t)svo_scene_height(N, seed, amp_num, x, z);
+  /* min/max pyramid, level l = cells of 8<<l */
+  int nlev = 0;
+  while ((8 << nlev) <= N) nlev++;
+  s.nlev = nlev;
+  s.pmin = (uint16_t **)calloc((size_t)nlev, sizeof(uint16_t *));
+  s.pmax = (uint16_t **)calloc((size_t)nlev, sizeof(uint16_t *));
+  for (int l = 0; l < nlev; l++) {
+    int cs = 8 << l, w = N / cs;
+    s.pmin[l] = (uint16_t *)malloc((size_t)w * w * 2);
+    s.pmax[l] = (uint16_t *)malloc((size_t)w * w * 2);
+    if (l == 0) {
+#pragma omp parallel for schedule(static)
+      for (int cz = 0; cz < w; cz++)
+        for (int cx = 0; cx < w; cx++) {
+          int mn = 65535, mx = 0;
+          for (int z = cz * 8; z < cz * 8 + 8; z++)
+            for (int x = cx * 8; x < cx * 8 + 8; x++) {
+              int h = s.h[(size_t)z * N + x];
+              if (h < mn) mn = h;
+              if (h > mx) mx = h;
+            }
+          s.pmin[0][(size_t)cz * w + cx] = (uint16_t)mn;
+          s.pmax[0][(size_t)cz * w + cx] = (uint16_t)mx;
+        }
+    } else {
+      int w2 = w * 2;
+      for (int cz = 0; cz < w; cz++)
+        for (int cx = 0; cx < w; cx++) {
+          int mn = 65535, mx = 0;
+          for (int dz = 0; dz < 2; dz++)
+            for (int dx = 0; dx < 2; dx++) {
+              size_t i = (size_t)(cz * 2 + dz) * w2 + (cx * 2 + dx);
+              if (s.pmin[l - 1][i] < mn) mn = s.pmin[l - 1][i];
+              if (s.pmax[l - 1][i] > mx) mx = s.pmax[l - 1][i];
+            }
+          s.pmin[l][(size_t)cz * w + cx] = (uint16_t)mn;
+          s.pmax[l][(size_t)cz * w + cx] = (uint16_t)mx;
+        }
+    }
+  }
+
+  counts_t cnt;
+  memset(&cnt, 0, sizeof cnt);
+  buf_t pool = {0};
+  size_t root = put_node7(&pool, 1); /* createDummyHead / root, value 1 */
+  cnt.interior++;
+
+  if (N <= TASK_SIZE) {
+    build_children(&s, &pool, &cnt, root, 0, 0, 0, N);
+  } else {
+    int levels = 0;
+    while ((CHUNK_SIZE << levels) < N) levels++;
+    size_t nchunks_max = (size_t)1 << (3 * levels), nchunks = 0;
+    chunk_t *chunks = (chunk_t *)malloc(nchunks_max * sizeof(chunk_t));
+    fill_top(&pool, &cnt, root, levels, 0, 0, 0, chunks, &nchunks);
+    size_t ntasks = nchunks * 8;
+    buf_t *tb = (buf_t *)calloc(ntasks, sizeof(buf_t));
+    counts_t *tc = (counts_t *)calloc(ntasks, sizeof(counts_t));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long t = 0; t < (long)ntasks; t++) {
+      const chunk_t *c = &chunks[t / 8];
+      int i = (int)(t % 8);
+      int x = c->x + (i & 1) * TASK_SIZE, y = c->y + ((i >> 1) & 1) * TASK_SIZE, z = c->z + ((i >> 2) & 1) * TASK_SIZE;
+      size_t head = put_node7(&tb[t], 1); /* dummy head, OctreeThread.java:21 */
+      build_children(&s, &tb[t], &tc[t], head, x, y, z, TASK_SIZE);
+    }
+    /* splice, Octree.java:317-343 */
+    size_t total = pool.len;
+    for (size_t t = 0; t < ntasks; t++) total += tb[t].len - NODE_SIZE;
+    total += nchunks * 8 * NODE_SIZE;
+    if (total > 0x7fffffffULL) {
+      for (size_t t = 0; t < ntasks; t++) free(tb[t].d);
+      free(tb); free(tc); free(chunks); free(pool.d); free_scene(&s);
+      if (out_len) *out_len = total;
+      return 3; /* child pointers are signed 32-bit: pool must stay below 2^31 bytes */
+    }
+    buf_reserve(&pool, total - pool.len);
+    for (size_t c = 0; c < nchunks; c++) {
+      size_t ch[8];
+      for (int i = 0; i < 8; i++) { ch[i] = put_node7(&pool, 1); cnt.interior++; }
+      set_cp(pool.d, chunks[c].node_off, (int64_t)ch[0] - (int64_t)chunks[c].node_off);
+      for (int i = 0; i < 8; i++) {
+        buf_t *b = &tb[c * 8 + i];
+        set_cp(pool.d, ch[i], (int64_t)pool.len - (int64_t)ch[i]);
+        pool.d[ch[i] + 5] = b->d[5]; /* leaf mask of the dummy head */
+        pool.d[ch[i] + 6] = b->d[6];
+        memcpy(pool.d + pool.len, b->d + NODE_SIZE, b->len - NODE_SIZE);
+        pool.len += b->len - NODE_SIZE;
+        cnt.interior += tc[c * 8 + i].interior;
+        cnt.surface_leaf += tc[c * 8 + i].surface_leaf;
+        cnt.nonsurface_leaf += tc[c * 8 + i].nonsurface_leaf;
+        cnt.subdiv_leaf += tc[c * 8 + i].subdiv_leaf;
+        free(b->d);
+      }
+    }
+    free(tb); free(tc); free(chunks);
+  }
+
+  if (st) {
+    st->bytes = pool.len;
+    st->interior = cnt.interior; st->surface_leaf = cnt.surface_leaf;
+    st->nonsurface_leaf = cnt.nonsurface_leaf; st->subdiv_leaf = cnt.subdiv_leaf;
+    int d = 0;
+    while ((1 << d) < N) d++;
+    st->depth = d;
+    st->hmin = s.pmin[nlev - 1][0]; st->hmax = s.pmax[nlev - 1][0];
+  }
+  free_scene(&s);
+  *out_pool = pool.d;
+  *out_len = pool.len;
+  return 0;
+}
+
+void svo_scene_free(uint8_t *p) { free(p); }
+
+/* ---------------------------------------------------------------- validator */
+
+static inline int tag_size(int tag) { return tag == 1 ? LEAF_SIZE : tag == 3 ? NS_LEAF_SIZE : NODE_SIZE; }
+
+/*
+ * Walk every reachable node; check that child blocks lie inside the pool and count
+ * node types.  Returns 0 if consistent, else a negative error code; *max_depth gets
+ * the deepest level reached (root = 0).
+ */
+int svo_pool_validate(const uint8_t *pool, uint64_t len, svo_scene_stats *st, int *max_depth) {
+  typedef struct { uint64_t off; int depth; } item_t;
+  size_t cap = 1024, sp = 0;
+  item_t *stack = (item_t *)malloc(cap * sizeof(item_t));
+  counts_t cnt;
+  memset(&cnt, 0, sizeof cnt);
+  int maxd = 0, rc = 0;
+  if (len < NODE_SIZE) { free(stack); return -1; }
+  stack[sp].off = 0; stack[sp].depth = 0; sp++;
+  cnt.interior = 1;
+  while (sp) {
+    item_t it = stack[--sp];
+    const uint8_t *p = pool + it.off;
+    int32_t cp = (int32_t)((uint32_t)p[1] << 24 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 8 | p[4]);
+    uint16_t mask = (uint16_t)(p[5] << 8 | p[6]);
+    if (cp == 0) continue;
+    int64_t c = (int64_t)it.off + cp;
+    if (it.depth + 1 > maxd) maxd = it.depth + 1;
+    for (int n = 0; n < 8; n++) {
+      int tag = (mask >> (2 * n)) & 3, sz = tag_size(tag);
+      if (c < 0 || (uint64_t)c + (uint64_t)sz > len) { rc = -2; goto done; }
+      if (tag == 0) {
+        cnt.interior++;
+        if (sp + 1 >= cap) { cap *= 2; stack = (item_t *)realloc(stack, cap * sizeof(item_t)); }
+        if (pool[c] != 0 || 1) { stack[sp].off = (uint64_t)c; stack[sp].depth = it.depth + 1; sp++; }
+      } else if (tag == 1) cnt.surface_leaf++;
+      else if (tag == 2) cnt.subdiv_leaf++;
+      else cnt.nonsurface_leaf++;
+      c += sz;
+    }
+  }
+done:
+  free(stack);
+  if (st) {
+    st->bytes = len; st->interior = cnt.interior; st->surface_leaf = cnt.surface_leaf;
+    st->nonsurface_leaf = cnt.nonsurface_leaf; st->subdiv_leaf = cnt.subdiv_leaf;
+  }
+  if (max_depth) *max_depth = maxd;
+  return rc;
+}
