@@ -63,6 +63,7 @@ typedef struct svo_oracle_stats {
   uint64_t nan_rays;   /* casts whose origin or direction is entirely NaN (quirk Q7) */
   uint64_t iterations; /* loop iterations of counted rays */
   uint64_t alg_bytes;  /* 7 per cast (root record) + size of every fetched child record */
+  uint64_t max_iter;   /* largest iteration count of a counted ray */
 } svo_oracle_stats;
 
 typedef struct { float x, y, z; } vec3;
@@ -154,10 +155,18 @@ static float gexp2(float y) {
   return ldexpf(1.0f, (int)ip) * fmaf(o, fp, e);
 }
 /* svotrace.comp:26-29 */
-static float glsl_rand(float cx, float cy) {
-  float s = gsin(cx * 12.9898f + cy * 78.233f);
+static float rand_from_dot(float d) {
+  float s = gsin(d);
   float v = s * 43758.5453f;
   return v - floorf(v);
+}
+static float glsl_rand(float cx, float cy) { return rand_from_dot(cx * 12.9898f + cy * 78.233f); }
+/* rand(vec2(a, seed2 * k)) as the reference's compiler evaluates it: the two constant
+   factors of (seed2 * k) * 78.233 are folded into one float constant first (Mesa NIR
+   algebraic rule fmul(fmul(a, #b), #c) -> fmul(a, #b * #c)); observable from frame 7 on */
+static float glsl_rand_scaled(float a, float seed2, float k) {
+  float kc = k * 78.233f;
+  return rand_from_dot(a * 12.9898f + seed2 * kc);
 }
 
 /* ------------------------------------------------------------------ node decode */
@@ -361,6 +370,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
     c->st->rays++;
     c->st->iterations += iter > MAX_RAYCAST_ITERATIONS ? MAX_RAYCAST_ITERATIONS : iter;
     c->st->alg_bytes += bytes;
+    if (iter > c->st->max_iter) c->st->max_iter = iter;
   }
 
   /* pin P7: fields the reference leaves unwritten on its early returns behave as if
@@ -451,7 +461,7 @@ static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, vec3 o
       }
       normal = res.normal;
       vec3 hitpoint = res.voxelPos;
-      float r = glsl_rand(seed0 + glsl_rand(seed0, seed2 * 0.1f), seed1 + glsl_rand(seed1, seed2 * 0.02f));
+      float r = glsl_rand(seed0 + glsl_rand_scaled(seed0, seed2, 0.1f), seed1 + glsl_rand_scaled(seed1, seed2, 0.02f));
       float rand1 = (2.0f * PI_F) * r;
       vec3 w = normal;
       vec3 axis = fabsf(w.x) > 0.1f ? v3(0, 1, 0) : v3(1, 0, 0);
