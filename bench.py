@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X.
+
+Metric (BASELINE.json): Mrays/s (primary + 1 bounce) at 1920x1080 on an 8192^3 SVO.
+A "step" is one frame: every pixel's primary ray + its diffuse bounce (renderMode 0, the
+reference's GI mode, svotrace.comp:443-560) through the HIP path, pool resident in HBM.
+Rays = intersectOctree-equivalent casts actually performed (counted by an untimed
+counting pass of the same frame); value = rays of all ranks / wall time of K steps.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the SAME frame is split
+into bands of 8-pixel tile rows, one band per rank, pool replicated by one RCCL
+broadcast; every step ends with an RCCL all-gather of the colour and depth bands over
+xGMI, inside the timed region ("scaling": "strong").
+
+Also on the JSON line: roofline (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM)
+and cpu_baseline (the CPU oracle timed on a bounded pixel subsample of the same frame).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=8192, help="SVO resolution N (N^3 voxels)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--mode", type=int, default=0, help="renderMode: 0 = GI primary + bounce (metric), 2 = primary + shadow")
+    ap.add_argument("--bounces", type=int, default=2, help="path segments in mode 0 (2 = primary + 1 bounce)")
+    ap.add_argument("--camera", default="K1")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SVO_BENCH_PIPELINE", "0")))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle sample time (0 = skip)")
+    ap.add_argument("--hits", type=int, default=0, help="also store 16-byte hit records per pixel")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the SVO hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    from svo_raytracer_amd.tiles import band_rows
+
+    W, H = args.width, args.height
+    cam = CAMERAS[args.camera]
+    ctx = hiplib.HipContext(local_rank)
+
+    # ---- scene: built once on rank 0, replicated by one RCCL broadcast -------------------
+    t_build = time.time()
+    pool = None
+    if rank == 0:
+        pool, sstats = scene.build_scene(args.size)
+        nbytes = int(pool.size)
+    if world > 1:
+        nb = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device="cuda")
+        dist.broadcast(nb, 0)
+        nbytes = int(nb.item())
+        dpool = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            dpool.copy_(torch.from_numpy(pool))
+        dist.broadcast(dpool, 0)
+        torch.cuda.synchronize()
+        ctx.pool_upload_device(dpool.data_ptr(), nbytes)
+        del dpool
+        torch.cuda.empty_cache()
+    else:
+        ctx.pool_upload(pool)
+    t_build = time.time() - t_build
+
+    # ---- frame state -----------------------------------------------------------------------
+    ctx.resize(W, H)
+    ctx.set_camera(cam)
+    ctx.set_params(2, args.mode, nbytes, 0, args.bounces, 0, 1)  # frameNumber 2 = first frame (Main.java:16,275)
+    ctx.set_pipeline(args.pipeline)
+    y0, y1, rows_per_rank = band_rows(H, world, rank)
+    hp = rows_per_rank * world  # padded height so that every rank's band has the same size
+    color = torch.zeros((hp, W), dtype=torch.int32, device="cuda")
+    depth = torch.zeros((hp, W), dtype=torch.float32, device="cuda")
+    hits = torch.zeros((hp, W, 4), dtype=torch.int32, device="cuda") if args.hits else None
+    ctx.bind_outputs(color.data_ptr(), depth.data_ptr(), hits.data_ptr() if hits is not None else None)
+    ctx.set_hit_records(bool(args.hits))
+    ctx.set_rows(y0, y1)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    my_color = color[rank * rows_per_rank:(rank + 1) * rows_per_rank]
+    my_depth = depth[rank * rows_per_rank:(rank + 1) * rows_per_rank]
+
+    def step():
+        ctx.dispatch_async()
+        if world > 1:
+            dist.all_gather_into_tensor(color, my_color)
+            dist.all_gather_into_tensor(depth, my_depth)
+
+    # ---- ray count of the frame (untimed counting pass; identical image) -------------------
+    cstats = ctx.count_frame()
+    counts = torch.tensor([cstats["rays"], cstats["iterations"], cstats["alg_bytes"], cstats["pixels"],
+                           cstats["nan_rays"]], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts)
+    rays, iters, alg_bytes, pixels, nan_rays = [int(v) for v in counts.tolist()]
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- kernel time by HIP events on the dispatch stream (rank 0's band) -------------------
+    kms = ctx.time_frames(2, max(5, min(args.steps, 30)))
+    kernel_ms = float(np.mean(kms))
+    out_bytes_px = 8 + (16 if args.hits else 0)
+    my_alg = cstats["alg_bytes"] + cstats["pixels"] * out_bytes_px
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays * args.steps / elapsed / 1e6
+        achieved = my_alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "%d_%dx%d_m%d_p%d" % (args.size, W, H, args.mode, args.pipeline)
+                traffic = tj.get(key)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mrays/s (primary + 1 bounce) at 1920x1080, 8192^3 SVO",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), camera %s, "
+                            "pipeline %d, tile-row bands over %d GPU(s)" % (
+                                args.size, nbytes, W, H, args.mode,
+                                "primary + %d bounce" % (args.bounces - 1) if args.mode == 0 else "primary + shadow ray",
+                                args.camera, args.pipeline, world),
+                "rays_per_frame": rays, "iterations_per_ray": round(iters / max(rays, 1), 2),
+                "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": nan_rays,
+                "scene_build_s": round(t_build, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel_ms": round(kernel_ms, 4), "alg_bytes_per_launch": int(my_alg),
+            },
+        }
+        # ---- CPU baseline: the oracle on a bounded subsample of the same frame, 1 thread ----
+        if args.cpu_seconds > 0 and world == 1:
+            from oracle import oracle
+            probe = oracle.render(pool, W, H, cam, 2, args.mode, bounces=args.bounces, xstep=32, ystep=32,
+                                  want_hits=False)
+            t1 = time.perf_counter()
+            probe = oracle.render(pool, W, H, cam, 2, args.mode, bounces=args.bounces, xstep=32, ystep=32,
+                                  want_hits=False)
+            dt = max(time.perf_counter() - t1, 1e-4)
+            per_px = dt / max(probe["stats"]["pixels"], 1)
+            want_px = args.cpu_seconds / per_px
+            stepxy = max(1, int(np.ceil(np.sqrt(W * H / want_px))))
+            t1 = time.perf_counter()
+            smp = oracle.render(pool, W, H, cam, 2, args.mode, bounces=args.bounces, xstep=stepxy, ystep=stepxy,
+                                want_hits=False)
+            dt = time.perf_counter() - t1
+            crays = smp["stats"]["rays"]
+            line["cpu_baseline"] = {
+                "value": round(crays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                "sample": "every %dth pixel in x and y of the same frame (%d pixels, %d rays, %.1f s), "
+                          "single-threaded C oracle; host has %d cores" % (
+                              stepxy, smp["stats"]["pixels"], crays, dt, os.cpu_count() or 0),
+            }
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

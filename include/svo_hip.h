@@ -1,0 +1,143 @@
+/*
+ * svo_hip.h -- C ABI of libsvohip.so: the MI355X-native replacement for the reference's
+ * GPU compute path (src/shaders/svotrace.comp dispatched through LWJGL OpenGL).
+ *
+ * Every entry point replaces a piece of the reference's host <-> GPU interface; the
+ * citation after each declaration is the reference code it stands in for
+ * (paths relative to /root/reference).  Plain pointers and sizes only: this is what a
+ * JNI / FFI stub binds (see include/svo_hip_jni.h and INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SVO_E_* code otherwise;
+ *     svo_last_error() gives the text.  Nothing throws, nothing prints (the reference's
+ *     GL path polls glGetError and prints, Renderer.java:160-165; the Java twin keeps that).
+ *   - the library copies on upload / update and writes into caller memory on readback;
+ *     it never retains a caller pointer across calls.
+ *   - a context is bound to one GPU and is not re-entrant (the reference drives GL from
+ *     the single thread that owns the context, Window.java:40).
+ *   - the pool bytes are taken exactly as Octree.getByteBuffer() holds them
+ *     (Octree.java:68-176); no re-encoding happens at the boundary.
+ */
+#ifndef SVO_HIP_H
+#define SVO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_OK 0
+#define SVO_E_INVALID (-1)   /* bad argument (null, bad range, size <= 0) */
+#define SVO_E_NOPOOL (-2)    /* dispatch before a pool upload */
+#define SVO_E_HIP (-3)       /* a HIP runtime call failed */
+#define SVO_E_NODEVICE (-4)  /* no such GPU */
+#define SVO_E_TOOLARGE (-5)  /* pool >= 2^31 bytes: child pointers are signed 32-bit (Octree.java:162-168) */
+
+typedef struct svo_ctx svo_ctx;
+
+/* Per-pixel record of the FIRST cast of the pixel (the primary ray).  `pointer` is the
+ * byte offset of the hit node in the pool -- the "hit voxel ID"; 0 = miss (the
+ * convention of svobeam.comp:538,553; the live trace shader's store is commented out,
+ * svotrace.comp:728). */
+typedef struct svo_hit {
+  uint32_t pointer;
+  uint16_t raw_normal; /* leafMask field of the hit node = packed normal for surface leaves (svotrace.comp:382-388) */
+  uint8_t value;       /* material (svotrace.comp:404) */
+  uint8_t level;       /* MAX_SCALE - scale (svotrace.comp:408) */
+  uint32_t iter;       /* traversal iterations of that cast (svotrace.comp:405) */
+  float t;             /* res.t (svotrace.comp:403); 0 on a miss */
+} svo_hit;
+
+typedef struct svo_stats {
+  uint64_t pixels;
+  uint64_t rays;        /* intersectOctree-equivalent casts of the last counted frame (all-NaN rays excluded) */
+  uint64_t nan_rays;    /* casts whose origin or direction is entirely NaN: exited at once, reported iter = 1501 */
+  uint64_t iterations;  /* traversal loop iterations of the counted rays */
+  uint64_t alg_bytes;   /* algorithmic bytes: 7 per cast + size (7/3/7/1) of every fetched child record */
+  uint64_t max_iter;
+  float last_dispatch_ms; /* GPU time of the last svo_dispatch*, HIP events on the library's stream */
+  int32_t device;
+} svo_stats;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+/* replaces: GL context + Renderer singleton creation (Window.java:24-50, Renderer.java:14-36) */
+int svo_create(int device, svo_ctx **out);
+int svo_destroy(svo_ctx *ctx);
+const char *svo_last_error(const svo_ctx *ctx); /* replaces Renderer.printGLErrors, Renderer.java:160-165 */
+
+/* ---- SVO pool (SSBO binding 7) --------------------------------------------------- */
+/* replaces Renderer.addSSBO(7, buf) / updateSSBO(7, buf): glBufferData of the whole pool
+ * (Renderer.java:123-134, Main.java:122).  nbytes = bytes that are meaningful (memOffset);
+ * reads past them return 0 like the reference's zero-filled over-allocation. */
+int svo_pool_upload(svo_ctx *ctx, const void *host, uint64_t nbytes);
+/* replaces Renderer.updateSSBO(7, buf, start, end): glBufferSubData of [start, end)
+ * (Renderer.java:136-146, Main.java:349-350).  host_base points at byte 0 of the pool.
+ * start >= end is rejected like the reference does (it prints and returns). */
+int svo_pool_update(svo_ctx *ctx, const void *host_base, uint64_t start, uint64_t end);
+/* replaces Renderer.getSSBO: glGetBufferSubData (Renderer.java:148-150) */
+int svo_pool_download(svo_ctx *ctx, void *host, uint64_t nbytes);
+/* device-side view of the pool, for a multi-GPU broadcast straight into it (RCCL);
+ * svo_pool_reserve allocates without uploading. */
+int svo_pool_reserve(svo_ctx *ctx, uint64_t nbytes);
+/* same as svo_pool_upload but the source is device memory on the context's GPU (e.g. the
+ * receive buffer of an RCCL broadcast owned by torch) */
+int svo_pool_upload_device(svo_ctx *ctx, const void *dptr, uint64_t nbytes);
+int svo_pool_device_ptr(svo_ctx *ctx, void **dptr, uint64_t *nbytes);
+
+/* ---- per-frame state (the shader's uniforms) ------------------------------------- */
+/* replaces glUniform3fv(8,pos), (1..4, l1,l2,r1,r2) (Main.java:269-273); values as
+ * Camera.getUniform() returns them (Camera.java:142-151) */
+int svo_set_camera(svo_ctx *ctx, const float pos[3], const float l1[3], const float l2[3], const float r1[3],
+                   const float r2[3]);
+/* replaces glUniform1i(5 frameNumber | 6 renderMode | 9 bufferEnd | 11 useBeam)
+ * (Main.java:275-283).  bounces / mirror_mask / spp expose the shader's dormant
+ * features (svotrace.comp:444, 500-504, 668-670); the live behaviour is 2 / 0 / 1. */
+int svo_set_params(svo_ctx *ctx, int frame_number, int render_mode, int buffer_end, int use_beam, int bounces,
+                   uint32_t mirror_mask, int spp);
+/* replaces the image allocations: rgba8 WxH on unit 0, r32f WxH on unit 1 (Main.java:66-78) */
+int svo_resize(svo_ctx *ctx, int width, int height);
+/* multi-GPU screen-tile split: render only pixel rows [y0, y1) (multiples of 8 except
+ * the last); default = whole frame.  No reference equivalent (single GPU). */
+int svo_set_rows(svo_ctx *ctx, int y0, int y1);
+/* 0 = fused per-pixel kernel; 1 = wavefront pipeline (primary / compact / bounce / resolve).
+ * Both produce identical bytes. */
+int svo_set_pipeline(svo_ctx *ctx, int pipeline);
+/* record per-pixel svo_hit (costs 16 B/pixel of stores); default on */
+int svo_set_hit_records(svo_ctx *ctx, int enabled);
+
+/* ---- dispatch ------------------------------------------------------------------- */
+/* replaces Renderer.useProgram + dispatchCompute(traceShader, W/8, H/8, 1):
+ * glDispatchCompute + glMemoryBarrier (Renderer.java:114-121, Main.java:267,285).
+ * Returns when the frame is complete. */
+int svo_dispatch(svo_ctx *ctx);
+/* same, but only enqueues on the context's stream */
+int svo_dispatch_async(svo_ctx *ctx);
+int svo_sync(svo_ctx *ctx);
+/* run the frame once more with counters on and fill svo_stats (untimed diagnostic pass) */
+int svo_count_frame(svo_ctx *ctx, svo_stats *out);
+int svo_get_stats(svo_ctx *ctx, svo_stats *out);
+/* use a caller-owned hipStream_t (e.g. torch's current stream) instead of the library's */
+int svo_set_stream(svo_ctx *ctx, void *hip_stream);
+/* time `iters` back-to-back frames with HIP events on the dispatch stream after `warmup`
+ * untimed ones; per-frame milliseconds into ms[iters] */
+int svo_time_frames(svo_ctx *ctx, int warmup, int iters, float *ms);
+
+/* ---- readback ------------------------------------------------------------------- */
+/* replaces glGetTexImage of image 0 (rgba8; row 0 = p.y = 0, bytes R,G,B,A) and
+ * image 1 (r32f depth) (Main.java:132-146, svotrace.comp:726-727) */
+int svo_read_color(svo_ctx *ctx, void *rgba8);
+int svo_read_depth(svo_ctx *ctx, float *depth);
+int svo_read_hits(svo_ctx *ctx, svo_hit *hits);
+/* render into caller-owned device buffers (e.g. torch tensors that an RCCL all-gather then
+ * reads in place): color = u32 rgba8 [rows][W], depth = f32, hits = svo_hit (may be NULL ->
+ * hit records off).  Pixel (x, y) lands at element y*W + x, so the buffers must cover every
+ * row this context renders.  Passing color == NULL returns to library-owned images. */
+int svo_bind_outputs(svo_ctx *ctx, void *color, void *depth, void *hits);
+/* device pointers of the three output images (W*H elements each), for an RCCL gather */
+int svo_output_device_ptrs(svo_ctx *ctx, void **color, void **depth, void **hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVO_HIP_H */

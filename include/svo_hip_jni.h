@@ -1,0 +1,55 @@
+/*
+ * svo_hip_jni.h -- JNI-typed shim over include/svo_hip.h, exported by libsvohip.so.
+ *
+ * The reference reaches its GPU through LWJGL, whose natives take only primitives and
+ * `long` addresses of direct ByteBuffers (e.g. GL15C.glBufferData -> nglBufferData(target,
+ * size, memAddress(data), usage)).  The shim keeps that style, so no function here needs
+ * a JNIEnv call -- which is also why it compiles without jni.h (absent in the build image):
+ * the first two parameters (JNIEnv*, jclass) are opaque pointers that are never touched.
+ *
+ * Java side: integration/java/src/engine/HipRenderer.java (static native methods with
+ * these exact names; class src.engine.HipRenderer mirrors src.engine.Renderer,
+ * /root/reference/src/engine/Renderer.java:43-165).
+ */
+#ifndef SVO_HIP_JNI_H
+#define SVO_HIP_JNI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t jint;
+typedef int64_t jlong;
+typedef float jfloat;
+
+/* Renderer.getInstance() / GL context  ->  svo_create; returns the context handle, 0 on failure */
+jlong Java_src_engine_HipRenderer_nCreate(void *env, void *cls, jint device);
+jint Java_src_engine_HipRenderer_nDestroy(void *env, void *cls, jlong ctx);
+/* Renderer.printGLErrors (Renderer.java:160-165): address of a NUL-terminated ASCII string */
+jlong Java_src_engine_HipRenderer_nLastError(void *env, void *cls, jlong ctx);
+/* Renderer.addSSBO / updateSSBO(full) (Renderer.java:123-134): addr = memAddress(buffer) */
+jint Java_src_engine_HipRenderer_nPoolUpload(void *env, void *cls, jlong ctx, jlong addr, jlong nbytes);
+/* Renderer.updateSSBO(bind, data, start, end) (Renderer.java:136-146) */
+jint Java_src_engine_HipRenderer_nPoolUpdate(void *env, void *cls, jlong ctx, jlong base_addr, jlong start, jlong end);
+/* Renderer.getSSBO (Renderer.java:148-150) */
+jint Java_src_engine_HipRenderer_nPoolDownload(void *env, void *cls, jlong ctx, jlong addr, jlong nbytes);
+/* glUniform3fv(8 | 1..4) (Main.java:269-273) */
+jint Java_src_engine_HipRenderer_nSetCamera(void *env, void *cls, jlong ctx, jfloat px, jfloat py, jfloat pz,
+                                            jfloat l1x, jfloat l1y, jfloat l1z, jfloat l2x, jfloat l2y, jfloat l2z,
+                                            jfloat r1x, jfloat r1y, jfloat r1z, jfloat r2x, jfloat r2y, jfloat r2z);
+/* glUniform1i(5 | 6 | 9 | 11) (Main.java:275-283) + dormant path options */
+jint Java_src_engine_HipRenderer_nSetParams(void *env, void *cls, jlong ctx, jint frame_number, jint render_mode,
+                                            jint buffer_end, jint use_beam, jint bounces, jint mirror_mask, jint spp);
+/* texture allocation (Main.java:66-78) */
+jint Java_src_engine_HipRenderer_nResize(void *env, void *cls, jlong ctx, jint width, jint height);
+/* Renderer.dispatchCompute (Renderer.java:118-121) */
+jint Java_src_engine_HipRenderer_nDispatch(void *env, void *cls, jlong ctx);
+/* glGetTexImage (Main.java:132-146): addr = memAddress(direct buffer of W*H*4 / W*H*4 / W*H*16 bytes) */
+jint Java_src_engine_HipRenderer_nReadColor(void *env, void *cls, jlong ctx, jlong addr);
+jint Java_src_engine_HipRenderer_nReadDepth(void *env, void *cls, jlong ctx, jlong addr);
+jint Java_src_engine_HipRenderer_nReadHits(void *env, void *cls, jlong ctx, jlong addr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

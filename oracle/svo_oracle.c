@@ -317,7 +317,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
       float tz_center = one_half * tz_coef + tz_corner;
       if (t_min <= tv_max) {
         if (child.cp == 0) { ok = 1; break; }
-        if (tc_max < h) {
+        if (tc_max < h && scale >= 0 && scale <= MAX_SCALE) { /* guard: index is always 11..22 for pools <= 13 levels deep */
           octstack[scale].node = parent;
           octstack[scale].tmax = t_max;
         }

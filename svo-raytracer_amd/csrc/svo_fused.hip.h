@@ -1,0 +1,234 @@
+// svo_fused.hip.h -- pipeline 0: one wavefront per 8x8 pixel tile, whole path per lane.
+//
+// Same work decomposition as the reference dispatch (local_size 8x8 = 64 threads = exactly
+// one CDNA wavefront, svotrace.comp:648; grid ceil(W/8) x ceil(H/8), Main.java:108-109,285),
+// but tiles are handed to workgroups so that each XCD (own L2) walks one contiguous
+// band of the screen.
+#pragma once
+#include "svo_device.h"
+#include "svo_kernels.h"
+
+namespace svo {
+
+struct PathState {
+  V3 colour;
+  float depth;
+  // first cast of the pixel
+  bool hit; uint32_t pointer, value, raw, level, iter; float t;
+};
+
+__device__ __forceinline__ V3 sky_colour(V3 d) {
+  return mk(0.6725f - d.y * 0.4f, 0.8784f - d.y * 0.4f, 1.0f - d.y * 0.25f);
+}
+
+__device__ __forceinline__ void record_first(PathState &ps, const Cast &c) {
+  ps.hit = c.hit;
+  ps.pointer = c.hit ? c.pointer : 0u;
+  ps.value = c.hit ? c.value : 0u;
+  ps.raw = c.hit ? c.raw : 0u;
+  ps.level = c.hit ? c.level : 0u;
+  ps.iter = c.iter;
+  ps.t = c.hit ? c.t : 0.0f;
+}
+
+// Diffuse / mirror continuation of svotrace.comp:476-509 given the (possibly stale) normal.
+__device__ __forceinline__ V3 scatter(V3 d, V3 normal, float r, bool mirror) {
+  if (mirror) {
+    const float k = 2.0f * dot3(d, normal);
+    return mk(d.x - k * normal.x, d.y - k * normal.y, d.z - k * normal.z);
+  }
+  const float rand1 = (2.0f * 3.14159265359f) * r;
+  const V3 w = normal;
+  const V3 axis = __builtin_fabsf(w.x) > 0.1f ? mk(0.f, 1.f, 0.f) : mk(1.f, 0.f, 0.f);
+  const V3 u = normalize3(cross3(axis, w));
+  const V3 v = cross3(w, u);
+  const float cs = sincos_pinned<true>(rand1), sn = sincos_pinned<false>(rand1), om = 1.0f - r;
+  return normalize3(mk((u.x * cs + v.x * sn) + w.x * om, (u.y * cs + v.y * sn) + w.y * om,
+                       (u.z * cs + v.z * sn) + w.z * om));
+}
+
+// trace() of svotrace.comp:435-646 for one sample.
+template <bool kCount>
+__device__ __forceinline__ void trace_sample(const Pool &pool, WaveStack &stk, uint32_t lane, const Frame &f, V3 o,
+                                             V3 d, float seed0, float seed1, float seed2, PathState &ps, bool first,
+                                             V3 &out_colour, float &out_depth, Counters &cnt) {
+  const int mode = f.render_mode;
+  V3 colour = mk(0.f, 0.f, 0.f);
+  float depth = 0.0f;
+  if (mode == 0) {
+    V3 accum = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f);
+    // fields of the reference's `res` that survive a missed cast
+    V3 normal = mk(0.f, 0.f, 0.f), vpos = mk(0.f, 0.f, 0.f);
+    uint32_t value = 0;
+    const float r = pixel_rand(seed0, seed1, seed2);
+    for (int i = 0; i < f.bounces; i++) {
+      const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, i != 0, cnt);
+      if (i == 0 && first) record_first(ps, c);
+      if (!c.hit && i == 0) {
+        const V3 s = sky_colour(d);
+        accum = mk(accum.x + s.x, accum.y + s.y, accum.z + s.z);
+        break;
+      }
+      if (c.hit) { normal = c.normal; vpos = c.voxel_pos; value = c.value; }
+      const V3 nd = scatter(d, normal, r, ((f.mirror_mask >> (value & 31u)) & 1u) != 0u);
+      o = vpos;
+      d = nd;
+      const V3 mc = material_colour(value, mk(vpos.x - 1.0f, vpos.y - 1.0f, vpos.z - 1.0f));
+      if (c.hit) {
+        depth = c.t;
+        accum = mk(accum.x + mask.x * 0.0f, accum.y + mask.y * 0.0f, accum.z + mask.z * 0.0f);
+        mask = mk(mask.x * mc.x, mask.y * mc.y, mask.z * mc.z);
+        const float k = dot3(nd, normal);
+        mask = mk(mask.x * k, mask.y * k, mask.z * k);
+      } else {
+        const V3 sun = normalize3(mk(1.0f, 1.0f, 1.0f));
+        const float diff = acos_pinned(dot3(d, sun));
+        if (diff < 0.4f) accum = mk(accum.x + mask.x * 7.0f, accum.y + mask.y * 7.0f, accum.z + mask.z * 7.0f);
+        accum = mk(accum.x + mask.x * 1.0f, accum.y + mask.y * 1.0f, accum.z + mask.z * 1.0f);
+        depth = 0.0f;
+        break;
+      }
+    }
+    colour = accum;
+  } else if (mode == 1) {
+    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt);
+    if (first) record_first(ps, c);
+    depth = c.hit ? c.t : 0.0f;
+    if (c.hit) { const float g = 0.005f * (float)c.iter; colour = mk(g, g, g); }
+    else if (c.capped) colour = mk(0.3f, 0.3f, 0.6f);
+    else { const float g = 0.01f * (float)c.iter; colour = mk(g, g, g); }
+  } else if (mode == 2) {
+    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt);
+    if (first) record_first(ps, c);
+    if (c.hit) {
+      depth = c.t;
+      V3 mc = material_colour(c.value, mk(0.f, 0.f, 0.f));
+      const V3 sun = normalize3(mk(0.5f, 0.5f, 0.5f));
+      const float k = (c.level >= 10u ? dot3(c.normal, sun) : dot3(mk(0.f, 1.0f, 0.f), sun)) * 0.1f;
+      mc = mk(mc.x + k, mc.y + k, mc.z + k);
+      const float dist = c.t + 0.0f;
+      const float lg = exp2_pinned(dist * (-0.5f * 2.0f * 1.44269504f));
+      const float lb = exp2_pinned(dist * (-0.5f * 4.0f * 1.44269504f));
+      const float lr = exp2_pinned(dist * (-0.5f * 1.0f * 1.44269504f));
+      mc.x = lr * mc.x + (1.0f - lr) * 1.0f;
+      mc.y = lg * mc.y + (1.0f - lg) * 1.0f;
+      mc.z = lb * mc.z + (1.0f - lb) * 1.0f;
+      const Cast s = cast_ray<kCount>(pool, stk, lane, c.voxel_pos, sun, kMaxDepth, false, cnt);
+      if (s.hit && s.t > s.scale_exp2 * 1.73205080757f) {
+        mc = mk(mc.x - 0.2f, mc.y - 0.2f, mc.z - 0.2f);
+      } else if (s.iter > 260u) {
+        const float pen = (0.05f * (float)s.iter) / 100.0f;
+        mc = mk(mc.x - pen, mc.y - pen, mc.z - pen);
+      }
+      colour = mc;
+    } else {
+      depth = 0.0f;
+      colour = sky_colour(d);
+    }
+  } else if (mode == 3) {
+    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt);
+    if (first) record_first(ps, c);
+    if (c.hit) {
+      depth = c.t;
+      colour = mk(c.normal.x * 0.5f + 0.5f, c.normal.y * 0.5f + 0.5f, c.normal.z * 0.5f + 0.5f);
+    }
+  }
+  out_colour = colour;
+  out_depth = depth;
+}
+
+__device__ __forceinline__ V3 primary_direction(const Frame &f, int px, int py) {
+  const float u = ((float)px + 0.5f) / (float)f.width;
+  const float v = ((float)py + 0.5f) / (float)f.height;
+  const float *c = f.cam;
+  const V3 a = mk(mix_g(c[3], c[6], v), mix_g(c[4], c[7], v), mix_g(c[5], c[8], v));
+  const V3 b = mk(mix_g(c[9], c[12], v), mix_g(c[10], c[13], v), mix_g(c[11], c[14], v));
+  return normalize3(mk(mix_g(a.x, b.x, u), mix_g(a.y, b.y, u), mix_g(a.z, b.z, u)));
+}
+
+// blockIdx -> tile so that the 8 XCDs (blocks are dealt to them round-robin) each take a
+// contiguous band of tiles: neighbouring tiles share subtrees, and each XCD has its own L2.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles) {
+  const int per = (ntiles + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+__device__ __forceinline__ void store_pixel(const Frame &f, int px, int py, V3 fin, float depth, const PathState &ps,
+                                            uint32_t *color, float *depthbuf, uint4 *hits) {
+  if (px < 10 && py < 10) fin = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
+  const size_t o = (size_t)py * (size_t)f.width + (size_t)px;
+  color[o] = unorm8(fin.x) | (unorm8(fin.y) << 8) | (unorm8(fin.z) << 16) | 0xff000000u;
+  depthbuf[o] = depth;
+  if (f.write_hits) {
+    uint4 h;
+    h.x = ps.pointer;
+    h.y = (ps.raw & 0xffffu) | ((ps.value & 0xffu) << 16) | ((ps.level & 0xffu) << 24);
+    h.z = ps.iter;
+    h.w = __float_as_uint(ps.t);
+    hits[o] = h;
+  }
+}
+
+template <bool kCount>
+__global__ __launch_bounds__(64) void trace_fused_kernel(const uint8_t *__restrict__ pool_base, const Frame f,
+                                                         uint32_t *__restrict__ color, float *__restrict__ depthbuf,
+                                                         uint4 *__restrict__ hits, DeviceCounters *counters) {
+  __shared__ WaveStack stk;
+  const int tile = xcd_tile((int)blockIdx.x, f.ntiles);
+  if (tile >= f.ntiles) return;
+  const uint32_t lane = threadIdx.x;
+  const int tx = tile % f.tiles_x, ty = tile / f.tiles_x;
+  const int px = tx * 8 + (int)(lane & 7u);
+  const int py = f.y0 + ty * 8 + (int)(lane >> 3);
+  Counters cnt = {0, 0, 0, 0, 0};
+  const bool live = px < f.width && py < f.y1 && py < f.height;
+  if (live) {
+    Pool pool;
+    pool.base = pool_base;
+    pool.len = f.pool_len;
+    const V3 o = mk(f.cam[0], f.cam[1], f.cam[2]);
+    const V3 d = primary_direction(f, px, py);
+    PathState ps;
+    ps.hit = false; ps.pointer = 0; ps.value = 0; ps.raw = 0; ps.level = 0; ps.iter = 0; ps.t = 0.0f;
+    V3 fin = mk(0.f, 0.f, 0.f);
+    float depth = 0.0f;
+    const int spp = f.spp < 1 ? 1 : f.spp;
+    for (int s = 0; s < spp; s++) {
+      V3 col;
+      float dep;
+      trace_sample<kCount>(pool, stk, lane, f, o, d, (float)px, (float)py, (float)(f.frame_number + s), ps, s == 0, col,
+                           dep, cnt);
+      if (s == 0) depth = dep;
+      fin = mk(fin.x + col.x, fin.y + col.y, fin.z + col.z);
+    }
+    if (spp > 1) {
+      const float inv = 1.0f / (float)spp;
+      fin = mk(fin.x * inv, fin.y * inv, fin.z * inv);
+    }
+    store_pixel(f, px, py, fin, depth, ps, color, depthbuf, hits);
+  }
+  if (kCount) {
+    // wave-level reduction, one atomic per counter per wave
+    unsigned long long rays = cnt.rays, nans = cnt.nan_rays, its = cnt.iters, by = cnt.bytes, pix = live ? 1ull : 0ull;
+    unsigned int mx = cnt.max_iter;
+    for (int off = 32; off > 0; off >>= 1) {
+      rays += __shfl_down(rays, off);
+      nans += __shfl_down(nans, off);
+      its += __shfl_down(its, off);
+      by += __shfl_down(by, off);
+      pix += __shfl_down(pix, off);
+      const unsigned int m2 = __shfl_down(mx, off);
+      mx = m2 > mx ? m2 : mx;
+    }
+    if (lane == 0) {
+      atomicAdd(&counters->pixels, pix);
+      atomicAdd(&counters->rays, rays);
+      atomicAdd(&counters->nan_rays, nans);
+      atomicAdd(&counters->iterations, its);
+      atomicAdd(&counters->alg_bytes, by);
+      atomicMax(&counters->max_iter, mx);
+    }
+  }
+}
+
+}  // namespace svo

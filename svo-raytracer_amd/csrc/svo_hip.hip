@@ -1,0 +1,419 @@
+// svo_hip.hip -- C-ABI implementation of include/svo_hip.h (libsvohip.so).
+// The reference-side interface each entry point replaces is cited in the header.
+#include "../../include/svo_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "svo_fused.hip.h"
+#include "svo_wavefront.hip.h"
+
+using namespace svo;
+
+static_assert(sizeof(svo_hit) == 16, "svo_hit must be 16 bytes");
+
+struct svo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // pool
+  uint8_t *d_pool = nullptr;
+  uint64_t pool_len = 0, pool_cap = 0;
+  uint32_t dword0 = 0;
+  // frame state
+  float cam[15] = {1.5f, 1.5f, 2.0f, -1.6f, -0.9f, -1.f, -1.6f, 0.9f, -1.f, 1.6f, -0.9f, -1.f, 1.6f, 0.9f, -1.f};
+  int width = 0, height = 0, y0 = 0, y1 = 0;
+  bool rows_set = false;
+  int frame_number = 2, render_mode = 2, buffer_end = 0, use_beam = 0, bounces = 2, spp = 1;
+  uint32_t mirror_mask = 0;
+  int pipeline = 0;
+  int write_hits = 1;
+  // outputs
+  uint32_t *d_color = nullptr;
+  float *d_depth = nullptr;
+  uint4 *d_hits = nullptr;
+  bool external_outputs = false;
+  uint32_t *own_color = nullptr;
+  float *own_depth = nullptr;
+  uint4 *own_hits = nullptr;
+  DeviceCounters *d_counters = nullptr;
+  WavefrontBuffers wf;
+  svo_stats stats{};
+  std::string err;
+};
+
+static int fail(svo_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(ctx, SVO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+static constexpr uint64_t kPad = 64;  // zero bytes kept behind the pool (8-byte record loads may overhang)
+
+extern "C" {
+
+int svo_create(int device, svo_ctx **out) {
+  if (!out) return SVO_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SVO_E_NODEVICE;
+  svo_ctx *c = new svo_ctx();
+  c->device = device;
+  c->stats.device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipMalloc((void **)&c->d_counters, sizeof(DeviceCounters)) != hipSuccess) {
+    delete c;
+    return SVO_E_HIP;
+  }
+  *out = c;
+  return SVO_OK;
+}
+
+static void free_outputs(svo_ctx *c) {
+  if (c->own_color) (void)hipFree(c->own_color);
+  if (c->own_depth) (void)hipFree(c->own_depth);
+  if (c->own_hits) (void)hipFree(c->own_hits);
+  c->own_color = nullptr; c->own_depth = nullptr; c->own_hits = nullptr;
+  if (!c->external_outputs) { c->d_color = nullptr; c->d_depth = nullptr; c->d_hits = nullptr; }
+  wavefront_free(c->wf);
+}
+
+int svo_destroy(svo_ctx *c) {
+  if (!c) return SVO_E_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  free_outputs(c);
+  if (c->d_pool) (void)hipFree(c->d_pool);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return SVO_OK;
+}
+
+const char *svo_last_error(const svo_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+// ---------------------------------------------------------------- pool
+static int ensure_pool_capacity(svo_ctx *c, uint64_t need_len, bool keep) {
+  if (need_len >= 0x80000000ull) return fail(c, SVO_E_TOOLARGE, "pool must stay below 2^31 bytes");
+  const uint64_t need = need_len + kPad;
+  if (need <= c->pool_cap) return SVO_OK;
+  uint64_t ncap = keep ? std::max<uint64_t>(need, c->pool_cap + c->pool_cap / 4) : need;
+  uint8_t *np = nullptr;
+  HIPCHK(c, hipMalloc((void **)&np, ncap));
+  HIPCHK(c, hipMemsetAsync(np, 0, ncap, c->stream));
+  if (keep && c->d_pool && c->pool_len)
+    HIPCHK(c, hipMemcpyAsync(np, c->d_pool, c->pool_len, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->d_pool) HIPCHK(c, hipFree(c->d_pool));
+  c->d_pool = np;
+  c->pool_cap = ncap;
+  return SVO_OK;
+}
+
+static int refresh_dword0(svo_ctx *c) {
+  c->dword0 = 0;
+  if (c->pool_len >= 4) HIPCHK(c, hipMemcpy(&c->dword0, c->d_pool, 4, hipMemcpyDeviceToHost));
+  else if (c->pool_len > 0) HIPCHK(c, hipMemcpy(&c->dword0, c->d_pool, c->pool_len, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+
+int svo_pool_reserve(svo_ctx *c, uint64_t nbytes) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_pool_capacity(c, nbytes, false);
+  if (rc) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_pool, 0, c->pool_cap, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->pool_len = nbytes;
+  return SVO_OK;
+}
+
+int svo_pool_upload_device(svo_ctx *c, const void *dptr, uint64_t nbytes) {
+  if (!c || (!dptr && nbytes)) return fail(c, SVO_E_INVALID, "svo_pool_upload_device: null buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  int rc = ensure_pool_capacity(c, nbytes, false);
+  if (rc) return rc;
+  if (nbytes) HIPCHK(c, hipMemcpy(c->d_pool, dptr, nbytes, hipMemcpyDeviceToDevice));
+  HIPCHK(c, hipMemset(c->d_pool + nbytes, 0, c->pool_cap - nbytes));
+  c->pool_len = nbytes;
+  return refresh_dword0(c);
+}
+
+int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
+  if (!c || (!host && nbytes)) return fail(c, SVO_E_INVALID, "svo_pool_upload: null buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = ensure_pool_capacity(c, nbytes, false);
+  if (rc) return rc;
+  if (nbytes) HIPCHK(c, hipMemcpy(c->d_pool, host, nbytes, hipMemcpyHostToDevice));
+  // bytes behind the new end must read as zero
+  HIPCHK(c, hipMemset(c->d_pool + nbytes, 0, c->pool_cap - nbytes));
+  c->pool_len = nbytes;
+  return refresh_dword0(c);
+}
+
+int svo_pool_update(svo_ctx *c, const void *host_base, uint64_t start, uint64_t end) {
+  if (!c || !host_base) return fail(c, SVO_E_INVALID, "svo_pool_update: null buffer");
+  if (start >= end) return fail(c, SVO_E_INVALID, "Update SSBO error: Invalid parameters.");
+  if (!c->d_pool) return fail(c, SVO_E_NOPOOL, "svo_pool_update before svo_pool_upload");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (end > c->pool_len) {
+    int rc = ensure_pool_capacity(c, end, true);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipMemcpy(c->d_pool + start, (const uint8_t *)host_base + start, end - start, hipMemcpyHostToDevice));
+  if (end > c->pool_len) c->pool_len = end;
+  if (start < 4) return refresh_dword0(c);
+  return SVO_OK;
+}
+
+int svo_pool_download(svo_ctx *c, void *host, uint64_t nbytes) {
+  if (!c || !host) return fail(c, SVO_E_INVALID, "svo_pool_download: null buffer");
+  if (!c->d_pool) return fail(c, SVO_E_NOPOOL, "no pool");
+  if (nbytes > c->pool_len) nbytes = c->pool_len;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(host, c->d_pool, nbytes, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+
+int svo_pool_device_ptr(svo_ctx *c, void **dptr, uint64_t *nbytes) {
+  if (!c || !dptr) return SVO_E_INVALID;
+  *dptr = c->d_pool;
+  if (nbytes) *nbytes = c->pool_len;
+  // the caller may have written the pool through this pointer (RCCL broadcast): re-read dword 0
+  if (c->d_pool) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return refresh_dword0(c);
+  }
+  return SVO_OK;
+}
+
+// ---------------------------------------------------------------- frame state
+int svo_set_camera(svo_ctx *c, const float pos[3], const float l1[3], const float l2[3], const float r1[3],
+                   const float r2[3]) {
+  if (!c || !pos || !l1 || !l2 || !r1 || !r2) return fail(c, SVO_E_INVALID, "svo_set_camera: null vector");
+  memcpy(c->cam + 0, pos, 12); memcpy(c->cam + 3, l1, 12); memcpy(c->cam + 6, l2, 12);
+  memcpy(c->cam + 9, r1, 12); memcpy(c->cam + 12, r2, 12);
+  return SVO_OK;
+}
+
+int svo_set_params(svo_ctx *c, int frame_number, int render_mode, int buffer_end, int use_beam, int bounces,
+                   uint32_t mirror_mask, int spp) {
+  if (!c) return SVO_E_INVALID;
+  if (bounces < 1 || spp < 1) return fail(c, SVO_E_INVALID, "bounces and spp must be >= 1");
+  c->frame_number = frame_number; c->render_mode = render_mode; c->buffer_end = buffer_end; c->use_beam = use_beam;
+  c->bounces = bounces; c->mirror_mask = mirror_mask; c->spp = spp;
+  return SVO_OK;
+}
+
+int svo_resize(svo_ctx *c, int width, int height) {
+  if (!c || width <= 0 || height <= 0) return fail(c, SVO_E_INVALID, "svo_resize: bad size");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (width == c->width && height == c->height && c->own_color) return SVO_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_outputs(c);
+  const size_t n = (size_t)width * (size_t)height;
+  HIPCHK(c, hipMalloc((void **)&c->own_color, n * 4));
+  HIPCHK(c, hipMalloc((void **)&c->own_depth, n * 4));
+  HIPCHK(c, hipMalloc((void **)&c->own_hits, n * 16));
+  HIPCHK(c, hipMemset(c->own_color, 0, n * 4));
+  HIPCHK(c, hipMemset(c->own_depth, 0, n * 4));
+  HIPCHK(c, hipMemset(c->own_hits, 0, n * 16));
+  if (!c->external_outputs) { c->d_color = c->own_color; c->d_depth = c->own_depth; c->d_hits = c->own_hits; }
+  c->width = width; c->height = height;
+  if (!c->rows_set) { c->y0 = 0; c->y1 = height; }
+  return SVO_OK;
+}
+
+int svo_bind_outputs(svo_ctx *c, void *color, void *depth, void *hits) {
+  if (!c) return SVO_E_INVALID;
+  if (!color) {
+    c->external_outputs = false;
+    c->d_color = c->own_color; c->d_depth = c->own_depth; c->d_hits = c->own_hits;
+    return SVO_OK;
+  }
+  if (!depth) return fail(c, SVO_E_INVALID, "svo_bind_outputs: depth buffer required");
+  c->external_outputs = true;
+  c->d_color = (uint32_t *)color; c->d_depth = (float *)depth; c->d_hits = (uint4 *)hits;
+  return SVO_OK;
+}
+
+int svo_set_rows(svo_ctx *c, int y0, int y1) {
+  if (!c) return SVO_E_INVALID;
+  if (y0 < 0 || y1 < y0 || (y0 & 7)) return fail(c, SVO_E_INVALID, "svo_set_rows: need 0 <= y0 <= y1, y0 % 8 == 0");
+  c->y0 = y0; c->y1 = y1; c->rows_set = true;
+  return SVO_OK;
+}
+
+int svo_set_pipeline(svo_ctx *c, int pipeline) {
+  if (!c || pipeline < 0 || pipeline > 1) return fail(c, SVO_E_INVALID, "pipeline must be 0 or 1");
+  c->pipeline = pipeline;
+  return SVO_OK;
+}
+
+int svo_set_hit_records(svo_ctx *c, int enabled) {
+  if (!c) return SVO_E_INVALID;
+  c->write_hits = enabled ? 1 : 0;
+  return SVO_OK;
+}
+
+int svo_set_stream(svo_ctx *c, void *hip_stream) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) HIPCHK(c, hipStreamDestroy(c->stream));
+  c->stream = (hipStream_t)hip_stream;
+  c->own_stream = false;
+  return SVO_OK;
+}
+
+// ---------------------------------------------------------------- dispatch
+static int make_frame(svo_ctx *c, Frame &f) {
+  if (!c->d_pool || c->pool_len < 7) return fail(c, SVO_E_NOPOOL, "svo_dispatch: no pool uploaded");
+  if (!c->d_color) return fail(c, SVO_E_INVALID, "svo_dispatch: svo_resize not called");
+  memcpy(f.cam, c->cam, sizeof f.cam);
+  f.width = c->width; f.height = c->height;
+  f.y0 = std::min(c->y0, c->height);
+  f.y1 = std::min(c->y1, c->height);
+  f.frame_number = c->frame_number; f.render_mode = c->render_mode;
+  f.bounces = c->bounces; f.spp = c->spp; f.mirror_mask = c->mirror_mask;
+  f.pool_len = (uint32_t)c->pool_len;
+  f.dword0 = c->dword0;
+  f.tiles_x = (c->width + 7) / 8;
+  f.tiles_y = (f.y1 - f.y0 + 7) / 8;
+  f.ntiles = f.tiles_x * f.tiles_y;
+  f.write_hits = (c->write_hits && c->d_hits) ? 1 : 0;
+  return SVO_OK;
+}
+
+static int launch_frame(svo_ctx *c, bool count) {
+  Frame f;
+  int rc = make_frame(c, f);
+  if (rc) return rc;
+  if (f.ntiles <= 0) return SVO_OK;
+  if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
+  if (c->pipeline == 1 && !count) {
+    rc = wavefront_launch(c->wf, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, c->stream);
+    if (rc) return fail(c, SVO_E_HIP, std::string("wavefront pipeline: ") + hipGetErrorString((hipError_t)rc));
+    return SVO_OK;
+  }
+  const int per = (f.ntiles + 7) / 8;
+  dim3 grid((unsigned)(per * 8)), block(64);
+  if (count)
+    hipLaunchKernelGGL(trace_fused_kernel<true>, grid, block, 0, c->stream, c->d_pool, f, c->d_color, c->d_depth,
+                       c->d_hits, c->d_counters);
+  else
+    hipLaunchKernelGGL(trace_fused_kernel<false>, grid, block, 0, c->stream, c->d_pool, f, c->d_color, c->d_depth,
+                       c->d_hits, c->d_counters);
+  HIPCHK(c, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_dispatch_async(svo_ctx *c) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  return launch_frame(c, false);
+}
+
+int svo_sync(svo_ctx *c) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SVO_OK;
+}
+
+int svo_dispatch(svo_ctx *c) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  int rc = launch_frame(c, false);
+  if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->stats.last_dispatch_ms = ms;
+  return SVO_OK;
+}
+
+int svo_count_frame(svo_ctx *c, svo_stats *out) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = launch_frame(c, true);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  DeviceCounters h;
+  HIPCHK(c, hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+  c->stats.pixels = h.pixels; c->stats.rays = h.rays; c->stats.nan_rays = h.nan_rays;
+  c->stats.iterations = h.iterations; c->stats.alg_bytes = h.alg_bytes; c->stats.max_iter = h.max_iter;
+  if (out) *out = c->stats;
+  return SVO_OK;
+}
+
+int svo_get_stats(svo_ctx *c, svo_stats *out) {
+  if (!c || !out) return SVO_E_INVALID;
+  *out = c->stats;
+  return SVO_OK;
+}
+
+int svo_time_frames(svo_ctx *c, int warmup, int iters, float *ms) {
+  if (!c || iters <= 0 || !ms) return fail(c, SVO_E_INVALID, "svo_time_frames: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int i = 0; i < warmup; i++) {
+    int rc = launch_frame(c, false);
+    if (rc) return rc;
+  }
+  std::vector<hipEvent_t> ev((size_t)iters + 1);
+  for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
+  HIPCHK(c, hipEventRecord(ev[0], c->stream));
+  for (int i = 0; i < iters; i++) {
+    int rc = launch_frame(c, false);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(ev[(size_t)i + 1], c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < iters; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], ev[(size_t)i], ev[(size_t)i + 1]));
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  c->stats.last_dispatch_ms = ms[iters - 1];
+  return SVO_OK;
+}
+
+// ---------------------------------------------------------------- readback
+static int read_rows(svo_ctx *c, void *dst, const void *src, size_t elem) {
+  if (!dst) return fail(c, SVO_E_INVALID, "readback: null buffer");
+  if (!src) return fail(c, SVO_E_INVALID, "readback before svo_resize");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(dst, src, (size_t)c->width * (size_t)c->height * elem, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+int svo_read_color(svo_ctx *c, void *rgba8) { return c ? read_rows(c, rgba8, c->d_color, 4) : SVO_E_INVALID; }
+int svo_read_depth(svo_ctx *c, float *depth) { return c ? read_rows(c, depth, c->d_depth, 4) : SVO_E_INVALID; }
+int svo_read_hits(svo_ctx *c, svo_hit *hits) { return c ? read_rows(c, hits, c->d_hits, 16) : SVO_E_INVALID; }
+
+int svo_output_device_ptrs(svo_ctx *c, void **color, void **depth, void **hits) {
+  if (!c) return SVO_E_INVALID;
+  if (color) *color = c->d_color;
+  if (depth) *depth = c->d_depth;
+  if (hits) *hits = c->d_hits;
+  return SVO_OK;
+}
+
+}  // extern "C"

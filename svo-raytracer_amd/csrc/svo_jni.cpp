@@ -1,0 +1,52 @@
+// svo_jni.cpp -- JNI-typed shim (include/svo_hip_jni.h): forwards to the C ABI, nothing else.
+#include "../../include/svo_hip_jni.h"
+#include "../../include/svo_hip.h"
+
+extern "C" {
+
+jlong Java_src_engine_HipRenderer_nCreate(void *, void *, jint device) {
+  svo_ctx *c = nullptr;
+  if (svo_create(device, &c) != SVO_OK) return 0;
+  return (jlong)(intptr_t)c;
+}
+jint Java_src_engine_HipRenderer_nDestroy(void *, void *, jlong ctx) { return svo_destroy((svo_ctx *)(intptr_t)ctx); }
+jlong Java_src_engine_HipRenderer_nLastError(void *, void *, jlong ctx) {
+  return (jlong)(intptr_t)svo_last_error((svo_ctx *)(intptr_t)ctx);
+}
+jint Java_src_engine_HipRenderer_nPoolUpload(void *, void *, jlong ctx, jlong addr, jlong nbytes) {
+  return svo_pool_upload((svo_ctx *)(intptr_t)ctx, (const void *)(intptr_t)addr, (uint64_t)nbytes);
+}
+jint Java_src_engine_HipRenderer_nPoolUpdate(void *, void *, jlong ctx, jlong base, jlong start, jlong end) {
+  if (start < 0 || end < 0) return SVO_E_INVALID;
+  return svo_pool_update((svo_ctx *)(intptr_t)ctx, (const void *)(intptr_t)base, (uint64_t)start, (uint64_t)end);
+}
+jint Java_src_engine_HipRenderer_nPoolDownload(void *, void *, jlong ctx, jlong addr, jlong nbytes) {
+  return svo_pool_download((svo_ctx *)(intptr_t)ctx, (void *)(intptr_t)addr, (uint64_t)nbytes);
+}
+jint Java_src_engine_HipRenderer_nSetCamera(void *, void *, jlong ctx, jfloat px, jfloat py, jfloat pz, jfloat l1x,
+                                            jfloat l1y, jfloat l1z, jfloat l2x, jfloat l2y, jfloat l2z, jfloat r1x,
+                                            jfloat r1y, jfloat r1z, jfloat r2x, jfloat r2y, jfloat r2z) {
+  const float p[3] = {px, py, pz}, l1[3] = {l1x, l1y, l1z}, l2[3] = {l2x, l2y, l2z}, r1[3] = {r1x, r1y, r1z},
+              r2[3] = {r2x, r2y, r2z};
+  return svo_set_camera((svo_ctx *)(intptr_t)ctx, p, l1, l2, r1, r2);
+}
+jint Java_src_engine_HipRenderer_nSetParams(void *, void *, jlong ctx, jint frame_number, jint render_mode,
+                                            jint buffer_end, jint use_beam, jint bounces, jint mirror_mask, jint spp) {
+  return svo_set_params((svo_ctx *)(intptr_t)ctx, frame_number, render_mode, buffer_end, use_beam, bounces,
+                        (uint32_t)mirror_mask, spp);
+}
+jint Java_src_engine_HipRenderer_nResize(void *, void *, jlong ctx, jint w, jint h) {
+  return svo_resize((svo_ctx *)(intptr_t)ctx, w, h);
+}
+jint Java_src_engine_HipRenderer_nDispatch(void *, void *, jlong ctx) { return svo_dispatch((svo_ctx *)(intptr_t)ctx); }
+jint Java_src_engine_HipRenderer_nReadColor(void *, void *, jlong ctx, jlong addr) {
+  return svo_read_color((svo_ctx *)(intptr_t)ctx, (void *)(intptr_t)addr);
+}
+jint Java_src_engine_HipRenderer_nReadDepth(void *, void *, jlong ctx, jlong addr) {
+  return svo_read_depth((svo_ctx *)(intptr_t)ctx, (float *)(intptr_t)addr);
+}
+jint Java_src_engine_HipRenderer_nReadHits(void *, void *, jlong ctx, jlong addr) {
+  return svo_read_hits((svo_ctx *)(intptr_t)ctx, (svo_hit *)(intptr_t)addr);
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+// svo_kernels.h -- frame description shared by the kernels and the C-ABI host code.
+#pragma once
+#include <stdint.h>
+
+namespace svo {
+
+// Everything the reference passes as uniforms (svotrace.comp:5-18, Main.java:269-283)
+// plus the image size and the row range this GPU renders.
+struct Frame {
+  float cam[15];        // pos, l1, l2, r1, r2
+  int32_t width, height;
+  int32_t y0, y1;       // pixel rows [y0, y1) rendered by this launch
+  int32_t frame_number, render_mode;
+  int32_t bounces, spp;
+  uint32_t mirror_mask;
+  uint32_t pool_len;
+  uint32_t dword0;      // first dword of the pool (debug square colour, svotrace.comp:696-698)
+  int32_t tiles_x, tiles_y, ntiles;
+  int32_t write_hits;
+};
+
+// device-side counters of a counted frame
+struct DeviceCounters {
+  unsigned long long pixels, rays, nan_rays, iterations, alg_bytes;
+  unsigned int max_iter, pad;
+};
+
+}  // namespace svo

@@ -1,0 +1,226 @@
+"""ctypes binding of libsvohip.so (include/svo_hip.h).  Thin: one Python method per
+C-ABI entry point.  Fails loudly when the HIP library is missing -- there is no CPU
+fallback on the product path."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsvohip.so")
+
+HIT_DTYPE = np.dtype([("pointer", "<u4"), ("raw_normal", "<u2"), ("value", "u1"), ("level", "u1"),
+                      ("iter", "<u4"), ("t", "<f4")])
+
+EXPORTS = [
+    "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
+    "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows",
+    "svo_set_pipeline", "svo_set_hit_records", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
+    "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits",
+    "svo_output_device_ptrs",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("pixels", ctypes.c_uint64), ("rays", ctypes.c_uint64), ("nan_rays", ctypes.c_uint64),
+                ("iterations", ctypes.c_uint64), ("alg_bytes", ctypes.c_uint64), ("max_iter", ctypes.c_uint64),
+                ("last_dispatch_ms", ctypes.c_float), ("device", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"HIP library missing: {LIB_PATH} (run __graft_entry__.build()); "
+                               "the SVO hot path has no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.svo_create.argtypes = [ci, ctypes.POINTER(vp)]
+        L.svo_destroy.argtypes = [vp]
+        L.svo_last_error.argtypes = [vp]
+        L.svo_last_error.restype = ctypes.c_char_p
+        L.svo_pool_upload.argtypes = [vp, vp, u64]
+        L.svo_pool_update.argtypes = [vp, vp, u64, u64]
+        L.svo_pool_download.argtypes = [vp, vp, u64]
+        L.svo_pool_reserve.argtypes = [vp, u64]
+        L.svo_pool_upload_device.argtypes = [vp, vp, u64]
+        L.svo_bind_outputs.argtypes = [vp, vp, vp, vp]
+        L.svo_pool_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+        L.svo_set_camera.argtypes = [vp, fp, fp, fp, fp, fp]
+        L.svo_set_params.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.c_uint32, ci]
+        L.svo_resize.argtypes = [vp, ci, ci]
+        L.svo_set_rows.argtypes = [vp, ci, ci]
+        L.svo_set_pipeline.argtypes = [vp, ci]
+        L.svo_set_hit_records.argtypes = [vp, ci]
+        L.svo_dispatch.argtypes = [vp]
+        L.svo_dispatch_async.argtypes = [vp]
+        L.svo_sync.argtypes = [vp]
+        L.svo_count_frame.argtypes = [vp, ctypes.POINTER(Stats)]
+        L.svo_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+        L.svo_set_stream.argtypes = [vp, vp]
+        L.svo_time_frames.argtypes = [vp, ci, ci, fp]
+        L.svo_read_color.argtypes = [vp, vp]
+        L.svo_read_depth.argtypes = [vp, vp]
+        L.svo_read_hits.argtypes = [vp, vp]
+        L.svo_output_device_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        for n in EXPORTS:
+            if n != "svo_last_error":
+                getattr(L, n).restype = ci
+        _lib = L
+    return _lib
+
+
+class SvoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"svo error {code}: {msg}")
+        self.code = code
+
+
+class HipContext:
+    """One context per GPU (include/svo_hip.h)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        self._h = ctypes.c_void_p()
+        rc = self._L.svo_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            raise SvoError(rc, "svo_create failed (no GPU / bad device index)")
+        self.width = self.height = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SvoError(rc, self._L.svo_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.svo_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # pool
+    def pool_upload(self, pool):
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        self._chk(self._L.svo_pool_upload(self._h, pool.ctypes.data, pool.size))
+
+    def pool_update(self, pool, start, end):
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        self._chk(self._L.svo_pool_update(self._h, pool.ctypes.data, int(start), int(end)))
+
+    def pool_download(self, nbytes):
+        out = np.zeros(int(nbytes), dtype=np.uint8)
+        self._chk(self._L.svo_pool_download(self._h, out.ctypes.data, out.size))
+        return out
+
+    def pool_upload_device(self, dptr, nbytes):
+        self._chk(self._L.svo_pool_upload_device(self._h, ctypes.c_void_p(int(dptr)), int(nbytes)))
+
+    def bind_outputs(self, color_ptr, depth_ptr, hits_ptr=None):
+        self._chk(self._L.svo_bind_outputs(self._h, ctypes.c_void_p(color_ptr or 0), ctypes.c_void_p(depth_ptr or 0),
+                                           ctypes.c_void_p(hits_ptr or 0)))
+
+    def pool_reserve(self, nbytes):
+        self._chk(self._L.svo_pool_reserve(self._h, int(nbytes)))
+
+    def pool_device_ptr(self):
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        self._chk(self._L.svo_pool_device_ptr(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    # frame state
+    def set_camera(self, cam):
+        cam = np.ascontiguousarray(np.asarray(cam, dtype=np.float32).reshape(5, 3))
+        fp = ctypes.POINTER(ctypes.c_float)
+        ptrs = [cam[i].ctypes.data_as(fp) for i in range(5)]
+        self._chk(self._L.svo_set_camera(self._h, *ptrs))
+
+    def set_params(self, frame_number=2, render_mode=2, buffer_end=0, use_beam=0, bounces=2, mirror_mask=0, spp=1):
+        self._chk(self._L.svo_set_params(self._h, int(frame_number), int(render_mode), int(buffer_end), int(use_beam),
+                                         int(bounces), int(mirror_mask), int(spp)))
+
+    def resize(self, width, height):
+        self._chk(self._L.svo_resize(self._h, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def set_rows(self, y0, y1):
+        self._chk(self._L.svo_set_rows(self._h, int(y0), int(y1)))
+
+    def set_pipeline(self, p):
+        self._chk(self._L.svo_set_pipeline(self._h, int(p)))
+
+    def set_hit_records(self, on):
+        self._chk(self._L.svo_set_hit_records(self._h, 1 if on else 0))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._L.svo_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    # dispatch
+    def dispatch(self):
+        self._chk(self._L.svo_dispatch(self._h))
+
+    def dispatch_async(self):
+        self._chk(self._L.svo_dispatch_async(self._h))
+
+    def sync(self):
+        self._chk(self._L.svo_sync(self._h))
+
+    def count_frame(self):
+        st = Stats()
+        self._chk(self._L.svo_count_frame(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def stats(self):
+        st = Stats()
+        self._chk(self._L.svo_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def time_frames(self, warmup, iters):
+        ms = np.zeros(int(iters), dtype=np.float32)
+        self._chk(self._L.svo_time_frames(self._h, int(warmup), int(iters),
+                                          ms.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return ms
+
+    # readback
+    def read_color(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._chk(self._L.svo_read_color(self._h, out.ctypes.data))
+        return out
+
+    def read_depth(self):
+        out = np.zeros((self.height, self.width), dtype=np.float32)
+        self._chk(self._L.svo_read_depth(self._h, out.ctypes.data))
+        return out
+
+    def read_hits(self):
+        out = np.zeros((self.height, self.width), dtype=HIT_DTYPE)
+        self._chk(self._L.svo_read_hits(self._h, out.ctypes.data))
+        return out
+
+    def output_device_ptrs(self):
+        a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(self._L.svo_output_device_ptrs(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    # convenience used by tests / bench: one full frame, everything read back
+    def render(self, pool=None, width=None, height=None, cam=None, frame_number=2, render_mode=2, bounces=2,
+               mirror_mask=0, spp=1):
+        if pool is not None:
+            self.pool_upload(pool)
+        if width is not None:
+            self.resize(width, height)
+        if cam is not None:
+            self.set_camera(cam)
+        self.set_params(frame_number, render_mode, 0, 0, bounces, mirror_mask, spp)
+        self.dispatch()
+        return {"rgba": self.read_color(), "depth": self.read_depth(), "hits": self.read_hits()}

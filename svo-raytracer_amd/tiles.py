@@ -1,0 +1,26 @@
+"""Screen-tile sharding of one frame over the GPUs of a node.
+
+The unit is the reference's 8x8 work-group tile (svotrace.comp:648); a rank renders a
+contiguous band of tile rows, all bands padded to the same number of pixel rows so
+that one all-gather of equal chunks reassembles the frame."""
+
+TILE = 8
+
+
+def band_rows(height, world, rank):
+    """Rows [y0, y1) rendered by `rank`, and the (padded) rows every rank's band occupies."""
+    tile_rows = (height + TILE - 1) // TILE
+    per = (tile_rows + world - 1) // world
+    rows_per_rank = per * TILE
+    y0 = min(rank * rows_per_rank, ((height + TILE - 1) // TILE) * TILE)
+    y1 = min(height, y0 + rows_per_rank)
+    y1 = max(y1, y0)
+    return y0, y1, rows_per_rank
+
+
+def gather_bands(dist, full, rank, rows_per_rank):
+    """All-gather the equal-sized bands in place: `full` is [rows_per_rank * world, W, ...],
+    this rank's band already sits at its final position inside it."""
+    mine = full[rank * rows_per_rank:(rank + 1) * rows_per_rank]
+    dist.all_gather_into_tensor(full, mine)
+    return full
