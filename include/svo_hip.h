@@ -98,7 +98,8 @@ int svo_set_params(svo_ctx *ctx, int frame_number, int render_mode, int buffer_e
 /* replaces the image allocations: rgba8 WxH on unit 0, r32f WxH on unit 1 (Main.java:66-78) */
 int svo_resize(svo_ctx *ctx, int width, int height);
 /* multi-GPU screen-tile split: render only pixel rows [y0, y1) (multiples of 8 except
- * the last); default = whole frame.  No reference equivalent (single GPU). */
+ * the last); default = whole frame; svo_resize to a different size resets it.  No reference
+ * equivalent (single GPU). */
 int svo_set_rows(svo_ctx *ctx, int y0, int y1);
 /* 0 = fused per-pixel kernel; 1 = wavefront pipeline (primary / compact / bounce / resolve).
  * Both produce identical bytes. */

@@ -238,7 +238,7 @@ int svo_resize(svo_ctx *c, int width, int height) {
   HIPCHK(c, hipMemset(c->own_hits, 0, n * 16));
   if (!c->external_outputs) { c->d_color = c->own_color; c->d_depth = c->own_depth; c->d_hits = c->own_hits; }
   c->width = width; c->height = height;
-  if (!c->rows_set) { c->y0 = 0; c->y1 = height; }
+  c->y0 = 0; c->y1 = height; c->rows_set = false;  // a new image size resets the row band to the whole frame
   return SVO_OK;
 }
 
