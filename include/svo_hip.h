@@ -101,8 +101,9 @@ int svo_resize(svo_ctx *ctx, int width, int height);
  * the last); default = whole frame; svo_resize to a different size resets it.  No reference
  * equivalent (single GPU). */
 int svo_set_rows(svo_ctx *ctx, int y0, int y1);
-/* 0 = fused per-pixel kernel; 1 = wavefront pipeline (primary / compact / bounce / resolve).
- * Both produce identical bytes. */
+/* 0 = one thread per pixel (the reference's decomposition); 1 = persistent waves with lane
+ * refill and in-place bounce regeneration; 2 = stage-per-kernel wavefront tracing with
+ * compacted ray queues.  All three produce identical bytes. */
 int svo_set_pipeline(svo_ctx *ctx, int pipeline);
 /* record per-pixel svo_hit (costs 16 B/pixel of stores); default on */
 int svo_set_hit_records(svo_ctx *ctx, int enabled);

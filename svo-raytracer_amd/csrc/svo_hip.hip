@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "svo_fused.hip.h"
+#include "svo_persistent.hip.h"
 #include "svo_wavefront.hip.h"
 
 using namespace svo;
@@ -44,6 +45,7 @@ struct svo_ctx {
   uint4 *own_hits = nullptr;
   DeviceCounters *d_counters = nullptr;
   WavefrontBuffers wf;
+  PersistBuffers pb;
   svo_stats stats{};
   std::string err;
 };
@@ -88,6 +90,7 @@ static void free_outputs(svo_ctx *c) {
   c->own_color = nullptr; c->own_depth = nullptr; c->own_hits = nullptr;
   if (!c->external_outputs) { c->d_color = nullptr; c->d_depth = nullptr; c->d_hits = nullptr; }
   wavefront_free(c->wf);
+  persist_free(c->pb);
 }
 
 int svo_destroy(svo_ctx *c) {
@@ -263,7 +266,7 @@ int svo_set_rows(svo_ctx *c, int y0, int y1) {
 }
 
 int svo_set_pipeline(svo_ctx *c, int pipeline) {
-  if (!c || pipeline < 0 || pipeline > 1) return fail(c, SVO_E_INVALID, "pipeline must be 0 or 1");
+  if (!c || pipeline < 0 || pipeline > 2) return fail(c, SVO_E_INVALID, "pipeline must be 0, 1 or 2");
   c->pipeline = pipeline;
   return SVO_OK;
 }
@@ -310,6 +313,11 @@ static int launch_frame(svo_ctx *c, bool count) {
   if (f.ntiles <= 0) return SVO_OK;
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
   if (c->pipeline == 1 && !count) {
+    rc = persist_launch(c->pb, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, c->stream);
+    if (rc) return fail(c, SVO_E_HIP, std::string("persistent pipeline: ") + hipGetErrorString((hipError_t)rc));
+    return SVO_OK;
+  }
+  if (c->pipeline == 2 && !count) {
     rc = wavefront_launch(c->wf, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, c->stream);
     if (rc) return fail(c, SVO_E_HIP, std::string("wavefront pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;

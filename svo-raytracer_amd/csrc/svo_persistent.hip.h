@@ -1,0 +1,295 @@
+// svo_persistent.hip.h -- pipeline 1: persistent waves, whole paths, lane refill.
+//
+// Each wave keeps 64 traversals in flight.  A lane owns one PATH at a time: its primary
+// ray, then -- regenerated in place from the hit -- its bounce / shadow ray(s); when the
+// path ends the lane stores the pixel and takes the next pixel of its XCD's screen band.
+// Finished lanes are handled in rounds: once 3/8 of the lanes that were traversing
+// have stopped, those lanes shade together (ballot), regenerate or retire, and the
+// freed lanes are refilled with one atomic per wave (ballot + prefix count).  Compared
+// with one-thread-per-pixel (pipeline 0 = the reference's decomposition) no lane waits for
+// the slowest ray of its tile; compared with stage-per-kernel wavefront tracing
+// (pipeline 2) the bounce ray starts where its primary just warmed the caches, no path
+// state travels through HBM and the frame has one tail instead of one per stage.
+//
+// Work distribution: the tile list is cut into 8 contiguous bands, one per XCD (each XCD
+// has its own 4 MiB L2; neighbouring tiles walk the same subtrees).  A wave reads its XCD
+// id from the hardware register and draws from that band's counter, then steals from the
+// other bands.  Placement is only a locality hint: any wave may render any pixel.
+#pragma once
+#include "svo_fused.hip.h"
+#include "svo_trav.h"
+
+namespace svo {
+
+struct PersistArgs {
+  const uint8_t *pool;
+  Frame f;
+  uint32_t *color;
+  float *depth;
+  uint4 *hits;
+  float *facc;       // spp > 1: colour sums (3 planes of npix)
+  size_t npix;
+  uint32_t *heads;   // 8 band counters (pixel slots drawn so far)
+  int tiles_per_band;
+  int sample;
+};
+
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 7u;
+}
+
+__device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix, int px, int py, V3 col, float depth) {
+  if (a.f.spp <= 1) {
+    if (px < 10 && py < 10) col = a.f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
+    a.color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
+  } else {
+    float *fx = a.facc + pix, *fy = a.facc + a.npix + pix, *fz = a.facc + 2 * a.npix + pix;
+    if (a.sample == 0) { *fx = 0.0f + col.x; *fy = 0.0f + col.y; *fz = 0.0f + col.z; }
+    else { *fx = *fx + col.x; *fy = *fy + col.y; *fz = *fz + col.z; }
+  }
+  if (a.sample == 0) a.depth[pix] = depth;
+}
+
+template <int kMode>
+__global__ __launch_bounds__(64) void persist_kernel(const PersistArgs a) {
+  __shared__ WaveStack stk;
+  const uint32_t lane = threadIdx.x;
+  const Frame &f = a.f;
+  Pool pool;
+  pool.base = a.pool;
+  pool.len = f.pool_len;
+  const V3 cam_o = mk(f.cam[0], f.cam[1], f.cam[2]);
+  const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
+
+  Trav t;
+  int status = ST_IDLE;
+  uint32_t pix = 0, seg = 0;
+  int px = 0, py = 0;
+  // path state that outlives a cast
+  V3 d = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), accum = mk(0.f, 0.f, 0.f), normal = mk(0.f, 0.f, 0.f);
+  float r = 0.0f, depth = 0.0f;
+  uint32_t value = 0;
+
+  uint32_t band = xcc_id();
+  int bands_left = 8;
+
+  for (;;) {
+    // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
+    if (status >= ST_HIT) {
+      const Cast c = trav_result(t, status);
+      status = ST_IDLE;
+      if (seg == 0u && f.write_hits && a.sample == 0) {
+        uint4 h;
+        h.x = c.hit ? c.pointer : 0u;
+        h.y = c.hit ? ((c.raw & 0xffffu) | ((c.value & 0xffu) << 16) | ((c.level & 0xffu) << 24)) : 0u;
+        h.z = c.iter;
+        h.w = c.hit ? __float_as_uint(c.t) : 0u;
+        a.hits[pix] = h;
+      }
+      if (kMode == 0) {
+        if (seg == 0u && !c.hit) {
+          const V3 s = sky_colour(d);
+          persist_emit(a, pix, px, py, mk(0.0f + s.x, 0.0f + s.y, 0.0f + s.z), 0.0f);
+        } else {
+          V3 vpos = mk(0.f, 0.f, 0.f);
+          if (c.hit) { normal = c.normal; value = c.value; vpos = c.voxel_pos; }
+          const V3 nd = scatter(d, normal, r, ((f.mirror_mask >> (value & 31u)) & 1u) != 0u);
+          if (c.hit) {
+            const V3 mc = material_colour(value, mk(vpos.x - 1.0f, vpos.y - 1.0f, vpos.z - 1.0f));
+            depth = c.t;
+            accum = mk(accum.x + mask.x * 0.0f, accum.y + mask.y * 0.0f, accum.z + mask.z * 0.0f);
+            mask = mk(mask.x * mc.x, mask.y * mc.y, mask.z * mc.z);
+            const float k = dot3(nd, normal);
+            mask = mk(mask.x * k, mask.y * k, mask.z * k);
+            if ((int)seg + 1 >= f.bounces) {
+              persist_emit(a, pix, px, py, accum, depth);
+            } else {
+              d = nd;
+              seg++;
+              status = trav_init(pool, t, vpos, nd, true);
+            }
+          } else {
+            const V3 sun = normalize3(mk(1.0f, 1.0f, 1.0f));
+            const float diff = acos_pinned(dot3(nd, sun));
+            if (diff < 0.4f) accum = mk(accum.x + mask.x * 7.0f, accum.y + mask.y * 7.0f, accum.z + mask.z * 7.0f);
+            accum = mk(accum.x + mask.x * 1.0f, accum.y + mask.y * 1.0f, accum.z + mask.z * 1.0f);
+            persist_emit(a, pix, px, py, accum, 0.0f);
+          }
+        }
+      } else if (kMode == 1) {
+        V3 col;
+        if (c.hit) { const float g = 0.005f * (float)c.iter; col = mk(g, g, g); }
+        else if (c.capped) col = mk(0.3f, 0.3f, 0.6f);
+        else { const float g = 0.01f * (float)c.iter; col = mk(g, g, g); }
+        persist_emit(a, pix, px, py, col, c.hit ? c.t : 0.0f);
+      } else if (kMode == 2) {
+        if (seg == 0u) {
+          if (c.hit) {
+            V3 mc = material_colour(c.value, mk(0.f, 0.f, 0.f));
+            const float k = (c.level >= 10u ? dot3(c.normal, sun2) : dot3(mk(0.f, 1.0f, 0.f), sun2)) * 0.1f;
+            mc = mk(mc.x + k, mc.y + k, mc.z + k);
+            const float dist = c.t + 0.0f;
+            const float lg = exp2_pinned(dist * (-0.5f * 2.0f * 1.44269504f));
+            const float lb = exp2_pinned(dist * (-0.5f * 4.0f * 1.44269504f));
+            const float lr = exp2_pinned(dist * (-0.5f * 1.0f * 1.44269504f));
+            mc.x = lr * mc.x + (1.0f - lr) * 1.0f;
+            mc.y = lg * mc.y + (1.0f - lg) * 1.0f;
+            mc.z = lb * mc.z + (1.0f - lb) * 1.0f;
+            mask = mc;
+            depth = c.t;
+            seg = 1u;
+            status = trav_init(pool, t, c.voxel_pos, sun2, false);
+          } else {
+            persist_emit(a, pix, px, py, sky_colour(d), 0.0f);
+          }
+        } else {
+          V3 mc = mask;
+          if (c.hit && c.t > c.scale_exp2 * 1.73205080757f) {
+            mc = mk(mc.x - 0.2f, mc.y - 0.2f, mc.z - 0.2f);
+          } else if (c.iter > 260u) {
+            const float pen = (0.05f * (float)c.iter) / 100.0f;
+            mc = mk(mc.x - pen, mc.y - pen, mc.z - pen);
+          }
+          persist_emit(a, pix, px, py, mc, depth);
+        }
+      } else if (kMode == 3) {
+        if (c.hit) persist_emit(a, pix, px, py, mk(c.normal.x * 0.5f + 0.5f, c.normal.y * 0.5f + 0.5f,
+                                                   c.normal.z * 0.5f + 0.5f), c.t);
+        else persist_emit(a, pix, px, py, mk(0.f, 0.f, 0.f), 0.0f);
+      } else {
+        persist_emit(a, pix, px, py, mk(0.f, 0.f, 0.f), 0.0f);
+      }
+    }
+
+    // ---------------- refill idle lanes: ballot + prefix count, one atomic per wave
+    if (bands_left > 0) {
+      const unsigned long long idle = __ballot(status == ST_IDLE);
+      if (idle != 0ull) {
+        const uint32_t n = (uint32_t)__builtin_popcountll(idle);
+        const int leader = __builtin_ctzll(idle);
+        const int first_tile = (int)band * a.tiles_per_band;
+        int band_tiles = f.ntiles - first_tile;
+        band_tiles = band_tiles < 0 ? 0 : (band_tiles > a.tiles_per_band ? a.tiles_per_band : band_tiles);
+        const uint32_t band_total = (uint32_t)band_tiles * 64u;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(a.heads + band, n);
+        base = (uint32_t)__shfl((int)base, leader);
+        const uint32_t slot =
+            base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        if (status == ST_IDLE && slot < band_total) {
+          const int tile = first_tile + (int)(slot >> 6);
+          const uint32_t l = slot & 63u;
+          px = (tile % f.tiles_x) * 8 + (int)(l & 7u);
+          py = f.y0 + (tile / f.tiles_x) * 8 + (int)(l >> 3);
+          if (px < f.width && py < f.y1 && py < f.height) {
+            pix = (uint32_t)py * (uint32_t)f.width + (uint32_t)px;
+            d = primary_direction(f, px, py);
+            seg = 0u;
+            mask = mk(1.f, 1.f, 1.f);
+            accum = mk(0.f, 0.f, 0.f);
+            normal = mk(0.f, 0.f, 0.f);
+            value = 0u;
+            depth = 0.0f;
+            if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
+            status = trav_init(pool, t, cam_o, d, false);
+          }
+        }
+        if (base + n >= band_total) {  // this band is used up: move on (work stealing)
+          band = (band + 1u) & 7u;
+          bands_left--;
+        }
+      }
+    }
+    if (__ballot(status != ST_IDLE) == 0ull) {
+      if (bands_left > 0) continue;
+      break;
+    }
+
+    // ---------------- traverse until enough lanes have stopped to make a round worthwhile
+    const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
+    const int threshold = bands_left > 0 ? (active0 * 5) / 8 : 0;
+    for (;;) {
+      if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t);
+      const int active = __builtin_popcountll(__ballot(status == ST_ACTIVE));
+      if (active <= threshold) break;
+    }
+  }
+}
+
+struct PersistBuffers {
+  uint32_t *heads = nullptr;
+  float *facc = nullptr;
+  size_t npix = 0;
+  int blocks = 0;
+};
+
+inline void persist_free(PersistBuffers &b) {
+  if (b.heads) (void)hipFree(b.heads);
+  if (b.facc) (void)hipFree(b.facc);
+  b = PersistBuffers();
+}
+
+template <int kMode>
+inline void persist_launch_mode(const PersistArgs &a, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(persist_kernel<kMode>, dim3((unsigned)blocks), dim3(64), 0, stream, a);
+}
+
+__global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t npix, uint32_t *color) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = f.y0 + blockIdx.y;
+  if (x >= f.width || y >= f.y1 || y >= f.height) return;
+  const size_t pix = (size_t)y * f.width + x;
+  const float inv = 1.0f / (float)f.spp;
+  V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
+  if (x < 10 && y < 10) col = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
+  color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
+}
+
+inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f, uint32_t *color, float *depth,
+                          uint4 *hits, hipStream_t stream) {
+  const size_t npix = (size_t)f.width * (size_t)f.height;
+  hipError_t e;
+  if (!b.heads) {
+    if ((e = hipMalloc((void **)&b.heads, 64 * sizeof(uint32_t))) != hipSuccess) return (int)e;
+    int dev = 0, cus = 256, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel<0>, 64, 0) != hipSuccess || per_cu < 1)
+      per_cu = 16;
+    b.blocks = cus * per_cu;
+  }
+  const int spp = f.spp < 1 ? 1 : f.spp;
+  if (spp > 1 && b.npix != npix) {
+    if (b.facc) (void)hipFree(b.facc);
+    b.facc = nullptr;
+    if ((e = hipMalloc((void **)&b.facc, npix * 3 * sizeof(float))) != hipSuccess) return (int)e;
+    b.npix = npix;
+  }
+  PersistArgs a;
+  a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = b.facc; a.npix = npix;
+  a.heads = b.heads;
+  a.tiles_per_band = (f.ntiles + 7) / 8;
+  const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
+  for (int s = 0; s < spp; s++) {
+    if ((e = hipMemsetAsync(b.heads, 0, 64 * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
+    a.sample = s;
+    switch (f.render_mode) {
+      case 0: persist_launch_mode<0>(a, blocks, stream); break;
+      case 1: persist_launch_mode<1>(a, blocks, stream); break;
+      case 2: persist_launch_mode<2>(a, blocks, stream); break;
+      case 3: persist_launch_mode<3>(a, blocks, stream); break;
+      default: persist_launch_mode<4>(a, blocks, stream); break;
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  }
+  if (spp > 1) {
+    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.y1 - f.y0));
+    hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, b.facc, npix, color);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+}  // namespace svo

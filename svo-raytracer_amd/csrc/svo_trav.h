@@ -1,0 +1,176 @@
+// svo_trav.h -- the cast of svo_device.h cut into init / step / result pieces so that a
+// persistent wave can keep 64 traversals in flight and swap finished rays for new ones
+// between steps.  Same arithmetic, same order, as cast_ray() (svotrace.comp:211-432).
+#pragma once
+#include "svo_device.h"
+
+namespace svo {
+
+// Traversal state of one ray, held in registers across refill rounds.
+struct Trav {
+  float cx, cy, cz, bx, by, bz;
+  float px, py, pz;
+  float t_min, t_max, h, sexp;
+  int scale, max_depth;
+  float cone_t;   // t_min beyond which a cone (secondary) ray drops to LOD 11; +inf for other rays
+  uint32_t idx, octant, pbase, pmask, written, iter;
+  uint32_t cptr, tag;
+  uint64_t rec;
+};
+
+enum : int { ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, ST_CAPPED = 4 };
+
+// set-up part of the cast (svotrace.comp:221-260)
+__device__ __forceinline__ int trav_init(const Pool &pool, Trav &t, V3 o, V3 d, const bool cone) {
+  t.cone_t = cone ? 0.05f : __builtin_inff();
+  t.iter = 0; t.cptr = 0; t.tag = 0; t.rec = 0; t.written = 0; t.max_depth = kMaxDepth;
+  t.scale = kMaxScale - 1; t.sexp = 0.5f;
+  if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
+    t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0; t.idx = 0;
+    t.cx = t.cy = t.cz = t.bx = t.by = t.bz = 0.0f; t.px = t.py = t.pz = 1.0f; t.pbase = 0; t.pmask = 0;
+    return ST_CAPPED;
+  }
+  if (__builtin_fabsf(d.x) < kEpsilon) d.x = kEpsilon * sign_g(d.x);
+  if (__builtin_fabsf(d.y) < kEpsilon) d.y = kEpsilon * sign_g(d.y);
+  if (__builtin_fabsf(d.z) < kEpsilon) d.z = kEpsilon * sign_g(d.z);
+  t.cx = 1.0f / -__builtin_fabsf(d.x);
+  t.cy = 1.0f / -__builtin_fabsf(d.y);
+  t.cz = 1.0f / -__builtin_fabsf(d.z);
+  t.bx = t.cx * o.x; t.by = t.cy * o.y; t.bz = t.cz * o.z;
+  t.octant = 0;
+  if (d.x > 0.0f) { t.octant ^= 1u; t.bx = 3.0f * t.cx - t.bx; }
+  if (d.y > 0.0f) { t.octant ^= 2u; t.by = 3.0f * t.cy - t.by; }
+  if (d.z > 0.0f) { t.octant ^= 4u; t.bz = 3.0f * t.cz - t.bz; }
+  t.t_min = fmax_g(fmax_g(2.0f * t.cx - t.bx, 2.0f * t.cy - t.by), 2.0f * t.cz - t.bz);
+  t.t_max = fmin_g(fmin_g(t.cx - t.bx, t.cy - t.by), t.cz - t.bz);
+  t.t_min = fmax_g(t.t_min, 0.0f);
+  t.h = t.t_max;
+  t.idx = 0; t.px = 1.0f; t.py = 1.0f; t.pz = 1.0f;
+  if (1.5f * t.cx - t.bx > t.t_min) { t.idx ^= 1u; t.px = 1.5f; }
+  if (1.5f * t.cy - t.by > t.t_min) { t.idx ^= 2u; t.py = 1.5f; }
+  if (1.5f * t.cz - t.bz > t.t_min) { t.idx ^= 4u; t.pz = 1.5f; }
+  const uint64_t root = load_record(pool, 0u);
+  t.pbase = rec_cp(root);
+  t.pmask = rec_mask_be(root);
+  return ST_ACTIVE;
+}
+
+// one iteration of the loop at svotrace.comp:262-369
+__device__ __forceinline__ int trav_step(const Pool &pool, WaveStack &stk, const uint32_t lane, Trav &t) {
+  t.iter++;
+  if (t.iter > kMaxIter) return ST_CAPPED;
+  if (t.t_min > t.cone_t) t.max_depth = 11;
+  const float tcx = t.px * t.cx - t.bx;
+  const float tcy = t.py * t.cy - t.by;
+  const float tcz = t.pz * t.cz - t.bz;
+  const float tc_max = fmin_g(fmin_g(tcx, tcy), tcz);
+  const uint32_t cs = t.idx ^ t.octant;
+  t.tag = (t.pmask >> (2u * cs)) & 3u;
+  t.cptr = t.pbase + child_offset(t.pmask, cs);
+  t.rec = load_record(pool, t.cptr);
+  if (rec_value(t.rec) != 0u && t.t_min <= t.t_max) {
+    if (kMaxScale - t.scale == t.max_depth) return ST_HIT;
+    const float tv_max = fmin_g(t.t_max, tc_max);
+    const float half = t.sexp * 0.5f;
+    const float tmx = half * t.cx + tcx;
+    const float tmy = half * t.cy + tcy;
+    const float tmz = half * t.cz + tcz;
+    if (t.t_min <= tv_max) {
+      const uint32_t ccp = t.tag == 0u ? rec_cp(t.rec) : 0u;
+      if (ccp == 0u) return ST_HIT;
+      if (tc_max < t.h) {
+        const int lv = t.scale - kStackBase;
+        if (lv >= 0 && lv < kStackLevels) {
+          stk.pm[lv * 64 + lane] = make_uint2(t.pbase, __float_as_uint(t.t_max));
+          stk.mk[lv * 64 + lane] = t.pmask;
+          t.written |= 1u << lv;
+        }
+      }
+      t.h = tc_max;
+      t.pbase = t.cptr + ccp;
+      t.pmask = rec_mask_be(t.rec);
+      t.idx = 0u;
+      --t.scale;
+      t.sexp = half;
+      if (tmx > t.t_min) { t.idx ^= 1u; t.px += t.sexp; }
+      if (tmy > t.t_min) { t.idx ^= 2u; t.py += t.sexp; }
+      if (tmz > t.t_min) { t.idx ^= 4u; t.pz += t.sexp; }
+      t.t_max = tv_max;
+      return ST_ACTIVE;
+    }
+  }
+  uint32_t step = 0u;
+  if (tcx <= tc_max) { step ^= 1u; t.px -= t.sexp; }
+  if (tcy <= tc_max) { step ^= 2u; t.py -= t.sexp; }
+  if (tcz <= tc_max) { step ^= 4u; t.pz -= t.sexp; }
+  t.t_min = tc_max;
+  t.idx ^= step;
+  if ((t.idx & step) != 0u) {
+    uint32_t diff = 0u;
+    if (step & 1u) diff |= __float_as_uint(t.px) ^ __float_as_uint(t.px + t.sexp);
+    if (step & 2u) diff |= __float_as_uint(t.py) ^ __float_as_uint(t.py + t.sexp);
+    if (step & 4u) diff |= __float_as_uint(t.pz) ^ __float_as_uint(t.pz + t.sexp);
+    t.scale = diff != 0u ? 31 - __builtin_clz(diff) : -1;
+    t.sexp = __uint_as_float(((uint32_t)t.scale - (uint32_t)kMaxScale + 127u) << 23);
+    if (t.scale < kMaxScale) {
+      const int lv = t.scale - kStackBase;
+      if (lv >= 0 && lv < kStackLevels && ((t.written >> lv) & 1u)) {
+        const uint2 e = stk.pm[lv * 64 + lane];
+        t.pbase = e.x;
+        t.t_max = __uint_as_float(e.y);
+        t.pmask = stk.mk[lv * 64 + lane];
+      } else if (t.scale >= 0) {
+        t.pbase = 0u; t.pmask = 0u; t.t_max = 0.0f;
+      }
+    }
+    const uint32_t sh = (uint32_t)t.scale & 31u;
+    const uint32_t sx = __float_as_uint(t.px) >> sh, sy = __float_as_uint(t.py) >> sh, sz = __float_as_uint(t.pz) >> sh;
+    t.px = __uint_as_float(sx << sh);
+    t.py = __uint_as_float(sy << sh);
+    t.pz = __uint_as_float(sz << sh);
+    t.idx = (sx & 1u) | ((sy & 1u) << 1) | ((sz & 1u) << 2);
+    t.h = 0.0f;
+    if (t.scale >= kMaxScale) return ST_MISS;
+  }
+  return ST_ACTIVE;
+}
+
+// result part of the cast (svotrace.comp:371-431)
+__device__ __forceinline__ Cast trav_result(const Trav &t, int status) {
+  Cast res;
+  res.hit = status == ST_HIT;
+  res.capped = status == ST_CAPPED;
+  res.pointer = 0; res.value = 0; res.raw = 0; res.level = 0;
+  res.normal = mk(0.f, 0.f, 0.f); res.voxel_pos = mk(0.f, 0.f, 0.f);
+  res.iter = t.iter;
+  res.t = t.t_min;
+  res.scale_exp2 = t.sexp;
+  if (!res.hit) return res;
+  uint32_t raw = 0u;
+  if (t.tag == 1u) raw = rec_normal_le(t.rec);
+  else if (t.tag != 3u) raw = rec_mask_be(t.rec);
+  V3 n = mk(0.f, 0.f, 0.f);
+  if (raw != 0u) {
+    const int r = (int)raw;
+    const float nx = (float)((r % 10) - 5);
+    const float ny = (float)((((r % 100) - (r % 10)) / 10) - 5);
+    const float nz = (float)(((r - (r % 100)) / 100) - 5);
+    n = normalize3(mk(nx, ny, nz));
+  }
+  res.pointer = t.cptr;
+  res.value = rec_value(t.rec);
+  res.raw = raw;
+  res.level = (uint32_t)(kMaxScale - t.scale);
+  res.normal = n;
+  float vx = t.px, vy = t.py, vz = t.pz;
+  if (t.octant & 1u) vx = 3.0f - vx - t.sexp;
+  if (t.octant & 2u) vy = 3.0f - vy - t.sexp;
+  if (t.octant & 4u) vz = 3.0f - vz - t.sexp;
+  vx += ((n.x * t.sexp) * 2.0f) * 1.74f;
+  vy += ((n.y * t.sexp) * 2.0f) * 1.74f;
+  vz += ((n.z * t.sexp) * 2.0f) * 1.74f;
+  res.voxel_pos = mk(vx, vy, vz);
+  return res;
+}
+
+}  // namespace svo

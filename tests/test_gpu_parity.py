@@ -10,7 +10,7 @@ from helpers import compare_with_golden, golden_case, golden_cases
 pytestmark = pytest.mark.gpu
 
 import os
-PIPELINES = [int(v) for v in os.environ.get("SVO_TEST_PIPELINES", "0,1").split(",")]
+PIPELINES = [int(v) for v in os.environ.get("SVO_TEST_PIPELINES", "0,1,2").split(",")]
 
 
 @pytest.fixture(scope="module")
