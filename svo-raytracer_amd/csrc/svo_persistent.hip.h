@@ -19,6 +19,8 @@
 #include "svo_fused.hip.h"
 #include "svo_trav.h"
 
+#include <cstdlib>
+
 namespace svo {
 
 struct PersistArgs {
@@ -32,6 +34,7 @@ struct PersistArgs {
   uint32_t *heads;   // 8 band counters (pixel slots drawn so far)
   int tiles_per_band;
   int sample;
+  int thresh_num;    // a round starts once active lanes <= thresh_num/8 of those active at its start
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -57,9 +60,7 @@ __global__ __launch_bounds__(64) void persist_kernel(const PersistArgs a) {
   __shared__ WaveStack stk;
   const uint32_t lane = threadIdx.x;
   const Frame &f = a.f;
-  Pool pool;
-  pool.base = a.pool;
-  pool.len = f.pool_len;
+  const BufPool pool = make_bufpool(a.pool, f.pool_len);
   const V3 cam_o = mk(f.cam[0], f.cam[1], f.cam[2]);
   const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64) void persist_kernel(const PersistArgs a) {
 
     // ---------------- traverse until enough lanes have stopped to make a round worthwhile
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
-    const int threshold = bands_left > 0 ? (active0 * 5) / 8 : 0;
+    const int threshold = bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0;
     for (;;) {
       if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t);
       const int active = __builtin_popcountll(__ballot(status == ST_ACTIVE));
@@ -223,6 +224,7 @@ struct PersistBuffers {
   float *facc = nullptr;
   size_t npix = 0;
   int blocks = 0;
+  int thresh_num = 4;
 };
 
 inline void persist_free(PersistBuffers &b) {
@@ -258,6 +260,9 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel<0>, 64, 0) != hipSuccess || per_cu < 1)
       per_cu = 16;
+    // tuning knobs (defaults are the shipped values)
+    if (const char *e1 = getenv("SVO_PERSIST_WAVES_PER_CU")) per_cu = atoi(e1) > 0 ? atoi(e1) : per_cu;
+    if (const char *e2 = getenv("SVO_PERSIST_THRESH")) b.thresh_num = atoi(e2);
     b.blocks = cus * per_cu;
   }
   const int spp = f.spp < 1 ? 1 : f.spp;
@@ -271,6 +276,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = b.facc; a.npix = npix;
   a.heads = b.heads;
   a.tiles_per_band = (f.ntiles + 7) / 8;
+  a.thresh_num = b.thresh_num;
   const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
   for (int s = 0; s < spp; s++) {
     if ((e = hipMemsetAsync(b.heads, 0, 64 * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;

@@ -1,10 +1,56 @@
 // svo_trav.h -- the cast of svo_device.h cut into init / step / result pieces so that a
 // persistent wave can keep 64 traversals in flight and swap finished rays for new ones
-// between steps.  Same arithmetic, same order, as cast_ray() (svotrace.comp:211-432).
+// between steps.  Same arithmetic, same order, as cast_ray() (svotrace.comp:211-432);
+// the instruction stream is trimmed for the issue-bound inner loop:
+//   * records come through a buffer descriptor (SGPR base + 32-bit lane offset, hardware
+//     range check: a pointer past the pool reads zeros, which is the reference's
+//     zero-filled over-allocation) instead of compare / select / 64-bit address math;
+//   * min / max are the bare v_min_f32 / v_max_f32 / v_min3_f32 (IEEE mode: a quiet NaN
+//     operand is ignored = GLSL-on-llvmpipe semantics); the builtins make the compiler
+//     canonicalise both inputs first (3 instructions per min);
+//   * the POP reads its stack slot unconditionally from a clamped level and selects.
 #pragma once
 #include "svo_device.h"
 
 namespace svo {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// The pool behind a buffer descriptor.  num_records covers the zero padding the
+// library keeps behind the pool, so an 8-byte read that starts inside never straddles.
+struct BufPool {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ BufPool make_bufpool(const uint8_t *base, uint32_t len) {
+  BufPool p;
+  p.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(len + 8u), 0x00020000);
+  return p;
+}
+__device__ __forceinline__ uint64_t load_record(const BufPool &pool, uint32_t p) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(pool.rsrc, (int)p, 0, 0);
+  return ((uint64_t)v.y << 32) | (uint64_t)v.x;
+}
 
 // Traversal state of one ray, held in registers across refill rounds.
 struct Trav {
@@ -21,7 +67,7 @@ struct Trav {
 enum : int { ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, ST_CAPPED = 4 };
 
 // set-up part of the cast (svotrace.comp:221-260)
-__device__ __forceinline__ int trav_init(const Pool &pool, Trav &t, V3 o, V3 d, const bool cone) {
+__device__ __forceinline__ int trav_init(const BufPool &pool, Trav &t, V3 o, V3 d, const bool cone) {
   t.cone_t = cone ? 0.05f : __builtin_inff();
   t.iter = 0; t.cptr = 0; t.tag = 0; t.rec = 0; t.written = 0; t.max_depth = kMaxDepth;
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
@@ -41,9 +87,9 @@ __device__ __forceinline__ int trav_init(const Pool &pool, Trav &t, V3 o, V3 d, 
   if (d.x > 0.0f) { t.octant ^= 1u; t.bx = 3.0f * t.cx - t.bx; }
   if (d.y > 0.0f) { t.octant ^= 2u; t.by = 3.0f * t.cy - t.by; }
   if (d.z > 0.0f) { t.octant ^= 4u; t.bz = 3.0f * t.cz - t.bz; }
-  t.t_min = fmax_g(fmax_g(2.0f * t.cx - t.bx, 2.0f * t.cy - t.by), 2.0f * t.cz - t.bz);
-  t.t_max = fmin_g(fmin_g(t.cx - t.bx, t.cy - t.by), t.cz - t.bz);
-  t.t_min = fmax_g(t.t_min, 0.0f);
+  t.t_min = vmax3(2.0f * t.cx - t.bx, 2.0f * t.cy - t.by, 2.0f * t.cz - t.bz);
+  t.t_max = vmin3(t.cx - t.bx, t.cy - t.by, t.cz - t.bz);
+  t.t_min = vmax(t.t_min, 0.0f);
   t.h = t.t_max;
   t.idx = 0; t.px = 1.0f; t.py = 1.0f; t.pz = 1.0f;
   if (1.5f * t.cx - t.bx > t.t_min) { t.idx ^= 1u; t.px = 1.5f; }
@@ -56,35 +102,34 @@ __device__ __forceinline__ int trav_init(const Pool &pool, Trav &t, V3 o, V3 d, 
 }
 
 // one iteration of the loop at svotrace.comp:262-369
-__device__ __forceinline__ int trav_step(const Pool &pool, WaveStack &stk, const uint32_t lane, Trav &t) {
+__device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, const uint32_t lane, Trav &t) {
   t.iter++;
   if (t.iter > kMaxIter) return ST_CAPPED;
   if (t.t_min > t.cone_t) t.max_depth = 11;
   const float tcx = t.px * t.cx - t.bx;
   const float tcy = t.py * t.cy - t.by;
   const float tcz = t.pz * t.cz - t.bz;
-  const float tc_max = fmin_g(fmin_g(tcx, tcy), tcz);
+  const float tc_max = vmin3(tcx, tcy, tcz);
   const uint32_t cs = t.idx ^ t.octant;
   t.tag = (t.pmask >> (2u * cs)) & 3u;
   t.cptr = t.pbase + child_offset(t.pmask, cs);
   t.rec = load_record(pool, t.cptr);
   if (rec_value(t.rec) != 0u && t.t_min <= t.t_max) {
     if (kMaxScale - t.scale == t.max_depth) return ST_HIT;
-    const float tv_max = fmin_g(t.t_max, tc_max);
-    const float half = t.sexp * 0.5f;
-    const float tmx = half * t.cx + tcx;
-    const float tmy = half * t.cy + tcy;
-    const float tmz = half * t.cz + tcz;
+    const float tv_max = vmin(t.t_max, tc_max);
     if (t.t_min <= tv_max) {
       const uint32_t ccp = t.tag == 0u ? rec_cp(t.rec) : 0u;
       if (ccp == 0u) return ST_HIT;
-      if (tc_max < t.h) {
-        const int lv = t.scale - kStackBase;
-        if (lv >= 0 && lv < kStackLevels) {
-          stk.pm[lv * 64 + lane] = make_uint2(t.pbase, __float_as_uint(t.t_max));
-          stk.mk[lv * 64 + lane] = t.pmask;
-          t.written |= 1u << lv;
-        }
+      const float half = t.sexp * 0.5f;
+      const float tmx = half * t.cx + tcx;
+      const float tmy = half * t.cy + tcy;
+      const float tmz = half * t.cz + tcz;
+      if (tc_max < t.h) {  // PUSH (scale is 11..22 for pools up to 13 levels; clamp keeps LDS accesses in range)
+        const uint32_t lvu = (uint32_t)(t.scale - kStackBase);
+        const uint32_t lv = lvu < (uint32_t)kStackLevels ? lvu : (uint32_t)(kStackLevels - 1);
+        stk.pm[lv * 64 + lane] = make_uint2(t.pbase, __float_as_uint(t.t_max));
+        stk.mk[lv * 64 + lane] = t.pmask;
+        t.written |= 1u << lv;
       }
       t.h = tc_max;
       t.pbase = t.cptr + ccp;
@@ -92,9 +137,9 @@ __device__ __forceinline__ int trav_step(const Pool &pool, WaveStack &stk, const
       t.idx = 0u;
       --t.scale;
       t.sexp = half;
-      if (tmx > t.t_min) { t.idx ^= 1u; t.px += t.sexp; }
-      if (tmy > t.t_min) { t.idx ^= 2u; t.py += t.sexp; }
-      if (tmz > t.t_min) { t.idx ^= 4u; t.pz += t.sexp; }
+      if (tmx > t.t_min) { t.idx ^= 1u; t.px += half; }
+      if (tmy > t.t_min) { t.idx ^= 2u; t.py += half; }
+      if (tmz > t.t_min) { t.idx ^= 4u; t.pz += half; }
       t.t_max = tv_max;
       return ST_ACTIVE;
     }
@@ -105,24 +150,24 @@ __device__ __forceinline__ int trav_step(const Pool &pool, WaveStack &stk, const
   if (tcz <= tc_max) { step ^= 4u; t.pz -= t.sexp; }
   t.t_min = tc_max;
   t.idx ^= step;
-  if ((t.idx & step) != 0u) {
+  if ((t.idx & step) != 0u) {  // POP
     uint32_t diff = 0u;
     if (step & 1u) diff |= __float_as_uint(t.px) ^ __float_as_uint(t.px + t.sexp);
     if (step & 2u) diff |= __float_as_uint(t.py) ^ __float_as_uint(t.py + t.sexp);
     if (step & 4u) diff |= __float_as_uint(t.pz) ^ __float_as_uint(t.pz + t.sexp);
-    t.scale = diff != 0u ? 31 - __builtin_clz(diff) : -1;
+    // diff != 0 always (pos and pos + cell size differ); v_ffbh of 0 would give scale 32 -> treated as exit
+    t.scale = 31 - __builtin_clz(diff | 1u);
     t.sexp = __uint_as_float(((uint32_t)t.scale - (uint32_t)kMaxScale + 127u) << 23);
-    if (t.scale < kMaxScale) {
-      const int lv = t.scale - kStackBase;
-      if (lv >= 0 && lv < kStackLevels && ((t.written >> lv) & 1u)) {
-        const uint2 e = stk.pm[lv * 64 + lane];
-        t.pbase = e.x;
-        t.t_max = __uint_as_float(e.y);
-        t.pmask = stk.mk[lv * 64 + lane];
-      } else if (t.scale >= 0) {
-        t.pbase = 0u; t.pmask = 0u; t.t_max = 0.0f;
-      }
-    }
+    // restore {child-block base, t_max, tag mask} of that level; a level this ray never pushed reads as the
+    // reference's zero-initialised stack entry
+    const uint32_t lvu = (uint32_t)(t.scale - kStackBase);
+    const uint32_t lv = lvu < (uint32_t)kStackLevels ? lvu : 0u;
+    const bool have = lvu < (uint32_t)kStackLevels && ((t.written >> lv) & 1u);
+    const uint2 e = stk.pm[lv * 64 + lane];
+    const uint32_t m = stk.mk[lv * 64 + lane];
+    t.pbase = have ? e.x : 0u;
+    t.t_max = have ? __uint_as_float(e.y) : 0.0f;
+    t.pmask = have ? m : 0u;
     const uint32_t sh = (uint32_t)t.scale & 31u;
     const uint32_t sx = __float_as_uint(t.px) >> sh, sy = __float_as_uint(t.py) >> sh, sz = __float_as_uint(t.pz) >> sh;
     t.px = __uint_as_float(sx << sh);

@@ -92,9 +92,7 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
   __shared__ WaveStack stk;
   const uint32_t lane = threadIdx.x;
   const Frame &f = a.f;
-  Pool pool;
-  pool.base = a.pool;
-  pool.len = f.pool_len;
+  const BufPool pool = make_bufpool(a.pool, f.pool_len);
   const uint32_t total = kPrimary ? (uint32_t)f.ntiles * 64u : *a.count_in;
   const bool cone = !kPrimary && f.render_mode == 0;
   const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
