@@ -167,7 +167,7 @@ struct Counters {
 // LDS stack of ONE wave: [level][lane].  pm = {child-block base, t_max bits}, mk = tag mask.
 struct WaveStack {
   uint2 pm[kStackLevels * 64];
-  uint32_t mk[kStackLevels * 64];
+  uint16_t mk[kStackLevels * 64];
 };
 
 template <bool kCount>
@@ -249,7 +249,7 @@ __device__ __forceinline__ Cast cast_ray(const Pool &pool, WaveStack &stk, const
           const int lv = scale - kStackBase;
           if (lv >= 0 && lv < kStackLevels) {
             stk.pm[lv * 64 + lane] = make_uint2(pbase, __float_as_uint(t_max));
-            stk.mk[lv * 64 + lane] = pmask;
+            stk.mk[lv * 64 + lane] = (uint16_t)pmask;
             written |= 1u << lv;
           }
         }

@@ -55,8 +55,11 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
   if (a.sample == 0) a.depth[pix] = depth;
 }
 
+#ifndef SVO_PERSIST_WAVES_PER_SIMD
+#define SVO_PERSIST_WAVES_PER_SIMD 5
+#endif
 template <int kMode>
-__global__ __launch_bounds__(64) void persist_kernel(const PersistArgs a) {
+__global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel(const PersistArgs a) {
   __shared__ WaveStack stk;
   const uint32_t lane = threadIdx.x;
   const Frame &f = a.f;

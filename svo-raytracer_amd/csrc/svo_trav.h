@@ -128,7 +128,7 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
         const uint32_t lvu = (uint32_t)(t.scale - kStackBase);
         const uint32_t lv = lvu < (uint32_t)kStackLevels ? lvu : (uint32_t)(kStackLevels - 1);
         stk.pm[lv * 64 + lane] = make_uint2(t.pbase, __float_as_uint(t.t_max));
-        stk.mk[lv * 64 + lane] = t.pmask;
+        stk.mk[lv * 64 + lane] = (uint16_t)t.pmask;
         t.written |= 1u << lv;
       }
       t.h = tc_max;
