@@ -7,10 +7,14 @@ reference's GI mode, svotrace.comp:443-560) through the HIP path, pool resident 
 Rays = intersectOctree-equivalent casts actually performed (counted by an untimed
 counting pass of the same frame); value = rays of all ranks / wall time of K steps.
 
-N > 1 (one process per GPU, launched by torch.distributed.run): the SAME frame is split
-into bands of 8-pixel tile rows, one band per rank, pool replicated by one RCCL
-broadcast; every step ends with an RCCL all-gather of the colour and depth bands over
-xGMI, inside the timed region ("scaling": "strong").
+N > 1 (one process per GPU, launched by torch.distributed.run).  The path shards by
+screen tile: the pool is replicated by one RCCL broadcast, every rank renders one band
+of 8-pixel tile rows, and each step's bands are gathered to rank 0 over xGMI (RCCL
+gather = one direct send per peer), overlapped with the next frame's traversal on a
+second stream.  Default --scaling weak: the per-GPU band stays 1920x1080 and the frame
+grows to 1920 x (1080*N) rows (same camera, denser rows), so per-GPU work is fixed.
+--scaling strong splits the SAME 1920x1080 frame into N bands instead; a 1.5 ms frame is
+then bounded by the longest single path (about 0.5 ms of dependent loads), see DESIGN.md.
 
 Also on the JSON line: roofline (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM)
 and cpu_baseline (the CPU oracle timed on a bounded pixel subsample of the same frame).
@@ -41,7 +45,9 @@ def parse():
     ap.add_argument("--mode", type=int, default=0, help="renderMode: 0 = GI primary + bounce (metric), 2 = primary + shadow")
     ap.add_argument("--bounces", type=int, default=2, help="path segments in mode 0 (2 = primary + 1 bounce)")
     ap.add_argument("--camera", default="K1")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SVO_BENCH_PIPELINE", "0")))
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SVO_BENCH_PIPELINE", "1")),
+                    help="0 one thread per pixel, 1 persistent waves (default), 2 staged wavefront")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle sample time (0 = skip)")
     ap.add_argument("--hits", type=int, default=0, help="also store 16-byte hit records per pixel")
     return ap.parse_args()
@@ -58,13 +64,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SVO hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_comm = os.environ.get("SVO_BENCH_FORCE_COMM", "0") == "1"  # exercise the RCCL path on one GPU
+    if world > 1 or (force_comm and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_comm = world > 1 or (force_comm and dist.is_initialized())
 
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
     from svo_raytracer_amd.cameras import CAMERAS
-    from svo_raytracer_amd.tiles import band_rows
+    from svo_raytracer_amd.tiles import band_rows, gather_bands_to_root
 
     W, H = args.width, args.height
     cam = CAMERAS[args.camera]
@@ -93,28 +101,44 @@ def main():
     t_build = time.time() - t_build
 
     # ---- frame state -----------------------------------------------------------------------
-    ctx.resize(W, H)
+    H_total = H * world if args.scaling == "weak" else H
+    ctx.resize(W, H_total)
     ctx.set_camera(cam)
     ctx.set_params(2, args.mode, nbytes, 0, args.bounces, 0, 1)  # frameNumber 2 = first frame (Main.java:16,275)
     ctx.set_pipeline(args.pipeline)
-    y0, y1, rows_per_rank = band_rows(H, world, rank)
+    y0, y1, rows_per_rank = band_rows(H_total, world, rank)
     hp = rows_per_rank * world  # padded height so that every rank's band has the same size
-    color = torch.zeros((hp, W), dtype=torch.int32, device="cuda")
-    depth = torch.zeros((hp, W), dtype=torch.float32, device="cuda")
+    nbuf = 2 if use_comm else 1  # double-buffered outputs: frame k is gathered while frame k+1 is traced
+    color = [torch.zeros((hp, W), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+    depth = [torch.zeros((hp, W), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     hits = torch.zeros((hp, W, 4), dtype=torch.int32, device="cuda") if args.hits else None
-    ctx.bind_outputs(color.data_ptr(), depth.data_ptr(), hits.data_ptr() if hits is not None else None)
     ctx.set_hit_records(bool(args.hits))
     ctx.set_rows(y0, y1)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
-    my_color = color[rank * rows_per_rank:(rank + 1) * rows_per_rank]
-    my_depth = depth[rank * rows_per_rank:(rank + 1) * rows_per_rank]
+    comm_stream = torch.cuda.Stream() if use_comm else None
+    gathered = [None] * nbuf  # event: the gather that last read buffer b has finished
+    state = {"k": 0}
 
     def step():
+        b = state["k"] % nbuf
+        state["k"] += 1
+        if gathered[b] is not None:
+            stream.wait_event(gathered[b])
+        ctx.bind_outputs(color[b].data_ptr(), depth[b].data_ptr(), hits.data_ptr() if hits is not None else None)
         ctx.dispatch_async()
-        if world > 1:
-            dist.all_gather_into_tensor(color, my_color)
-            dist.all_gather_into_tensor(depth, my_depth)
+        if use_comm:
+            done = torch.cuda.Event()
+            done.record(stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(done)
+                gather_bands_to_root(dist, color[b], rank, world, rows_per_rank, force=force_comm)
+                gather_bands_to_root(dist, depth[b], rank, world, rows_per_rank, force=force_comm)
+                ev = torch.cuda.Event()
+                ev.record(comm_stream)
+                gathered[b] = ev
+
+    ctx.bind_outputs(color[0].data_ptr(), depth[0].data_ptr(), hits.data_ptr() if hits is not None else None)
 
     # ---- ray count of the frame (untimed counting pass; identical image) -------------------
     cstats = ctx.count_frame()
@@ -165,13 +189,13 @@ def main():
             "metric": "Mrays/s (primary + 1 bounce) at 1920x1080, 8192^3 SVO",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "%d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), camera %s, "
-                            "pipeline %d, tile-row bands over %d GPU(s)" % (
-                                args.size, nbytes, W, H, args.mode,
+                            "pipeline %d, one %dx%d tile-row band per GPU, %d GPU(s), bands gathered to rank 0" % (
+                                args.size, nbytes, W, H_total, args.mode,
                                 "primary + %d bounce" % (args.bounces - 1) if args.mode == 0 else "primary + shadow ray",
-                                args.camera, args.pipeline, world),
+                                args.camera, args.pipeline, W, rows_per_rank, world),
                 "rays_per_frame": rays, "iterations_per_ray": round(iters / max(rays, 1), 2),
                 "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": nan_rays,
                 "scene_build_s": round(t_build, 1),
@@ -212,7 +236,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -24,3 +24,20 @@ def gather_bands(dist, full, rank, rows_per_rank):
     mine = full[rank * rows_per_rank:(rank + 1) * rows_per_rank]
     dist.all_gather_into_tensor(full, mine)
     return full
+
+
+def gather_bands_to_root(dist, full, rank, world, rows_per_rank, dst=0, force=False):
+    """Gather the equal-sized bands to rank `dst` only (the north-star exchange step: one
+    frame owner, every peer sends its band over its direct xGMI link).  `full` is
+    [rows_per_rank * world, W, ...] on every rank; only dst's copy ends up complete."""
+    mine = full[rank * rows_per_rank:(rank + 1) * rows_per_rank]
+    if world == 1 and not force:
+        return full
+    if rank == dst:
+        parts = [full[r * rows_per_rank:(r + 1) * rows_per_rank] for r in range(world)]
+        # the root's own band is already in place; give gather a scratch slot for it
+        parts[dst] = mine.clone()
+        dist.gather(mine, gather_list=parts, dst=dst)
+    else:
+        dist.gather(mine, gather_list=None, dst=dst)
+    return full

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from svo_raytracer_amd.tiles import band_rows, gather_bands
+from svo_raytracer_amd.tiles import band_rows, gather_bands, gather_bands_to_root
 
 
 def test_band_rows_cover_frame_exactly_once():
@@ -37,7 +37,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, out_path):
+def _worker(rank, world, port, w, h, out_path, to_root):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,22 +51,26 @@ def _worker(rank, world, port, w, h, out_path):
     depth = torch.zeros((rpr * world, w), dtype=torch.float32)
     color[y0:y1] = torch.from_numpy(band["rgba"].view(np.int32).reshape(h, w)[y0:y1].copy())
     depth[y0:y1] = torch.from_numpy(band["depth"][y0:y1].copy())
-    gather_bands(dist, color, rank, rpr)
-    gather_bands(dist, depth, rank, rpr)
+    if to_root:
+        gather_bands_to_root(dist, color, rank, world, rpr)
+        gather_bands_to_root(dist, depth, rank, world, rpr)
+    else:
+        gather_bands(dist, color, rank, rpr)
+        gather_bands(dist, depth, rank, rpr)
     if rank == 0:
         np.savez(out_path, color=color.numpy()[:h], depth=depth.numpy()[:h])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h", [96, 100])
-def test_two_rank_band_split_reassembles_the_frame(tmp_path, h):
+@pytest.mark.parametrize("h,to_root", [(96, False), (100, False), (96, True), (100, True)])
+def test_two_rank_band_split_reassembles_the_frame(tmp_path, h, to_root):
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd.cameras import CAMERAS
     from oracle import oracle
     w = 64
     out = str(tmp_path / "gathered.npz")
-    mp.spawn(_worker, args=(2, _free_port(), w, h, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), w, h, out, to_root), nprocs=2, join=True)
     z = np.load(out)
     pool, _ = scene.build_scene(64)
     full = oracle.render(pool, w, h, CAMERAS["K1"], 2, 0, want_hits=False)
