@@ -1,0 +1,179 @@
+package src.engine;
+
+import java.nio.ByteBuffer;
+import java.util.ArrayList;
+
+import org.lwjgl.system.MemoryUtil;
+
+/**
+ * Drop-in twin of {@link Renderer} for the SVO trace path: same method names and argument
+ * meaning, the work goes to libsvohip.so (MI355X) instead of the OpenGL compute shader.
+ *
+ * NOT COMPILED in the build image (no JDK there); shipped as the binding a maintainer adds.
+ * Natives are LWJGL-style: primitives and memAddress(...) longs only, so the C side
+ * (include/svo_hip_jni.h) needs no JNIEnv calls.
+ *
+ * Usage in Main.java: replace `Renderer.getInstance()` by `HipRenderer.getInstance()`, replace
+ * the raw glUniform* calls at Main.java:269-283 by setCamera(...) / setUniformInteger(...),
+ * and read the images back with readFramebuffer / readDepth instead of glGetTexImage.
+ */
+public class HipRenderer {
+
+  static {
+    System.loadLibrary("svohip");
+  }
+
+  private static final HipRenderer instance = new HipRenderer();
+  private final ArrayList<Shader> shaders = new ArrayList<Shader>();
+  private long ctx;
+  private int width, height;
+  private int frameNumber = 1, renderMode = 2, bufferEnd = 0, useBeam = 0;
+  private int bounces = 2, mirrorMask = 0, spp = 1;
+
+  public class Shader {
+    String name;
+    int computeProgram;
+    int computeProgramShader;
+
+    Shader(String name, int computeProgram, int computeProgramShader) {
+      this.name = name;
+      this.computeProgram = computeProgram;
+      this.computeProgramShader = computeProgramShader;
+    }
+  }
+
+  private HipRenderer() {
+    ctx = nCreate(0);
+    if (ctx == 0)
+      System.out.println("HIP ERR: no MI355X visible");
+  }
+
+  public static HipRenderer getInstance() {
+    return instance;
+  }
+
+  /** Renderer.addShader: "svotrace" binds to the precompiled HIP path; other shaders are inert. */
+  public Shader addShader(String name, String path) {
+    int id = (path.contains("svotrace") || name.equals("svotrace")) ? 1 : 0;
+    Shader shader = new Shader(name, id, id);
+    shaders.add(shader);
+    return shader;
+  }
+
+  /** glUniform1i: 5 frameNumber, 6 renderMode, 9 bufferEnd, 11 useBeamOptimization. */
+  public void setUniformInteger(int location, int value) {
+    if (location == 5) frameNumber = value;
+    else if (location == 6) renderMode = value;
+    else if (location == 9) bufferEnd = value;
+    else if (location == 11) useBeam = value;
+  }
+
+  /** glUniform3fv(8, pos), (1..4, l1, l2, r1, r2): pass Camera.getUniform(). */
+  public void setCamera(float[][] u) {
+    check(nSetCamera(ctx, u[0][0], u[0][1], u[0][2], u[1][0], u[1][1], u[1][2], u[2][0], u[2][1], u[2][2],
+        u[3][0], u[3][1], u[3][2], u[4][0], u[4][1], u[4][2]));
+  }
+
+  public void setImageSize(int w, int h) {
+    width = w;
+    height = h;
+  }
+
+  public void useProgram(Shader shader) {
+  }
+
+  /** glDispatchCompute + glMemoryBarrier: returns when the frame is complete. */
+  public void dispatchCompute(Shader shader, int numGroupsX, int numGroupsY, int numGroupsZ) {
+    if (shader == null || shader.computeProgram != 1)
+      return;
+    if (width == 0) {
+      width = numGroupsX * Constants.COMPUTE_GROUP_SIZE;
+      height = numGroupsY * Constants.COMPUTE_GROUP_SIZE;
+    }
+    check(nResize(ctx, width, height));
+    check(nSetParams(ctx, frameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+    check(nDispatch(ctx));
+  }
+
+  public void addSSBO(int bindIndex, ByteBuffer data) {
+    if (bindIndex != 7)
+      return;
+    check(nPoolUpload(ctx, MemoryUtil.memAddress(data), data.remaining()));
+  }
+
+  public void updateSSBO(int bindIndex, ByteBuffer data) {
+    addSSBO(bindIndex, data);
+  }
+
+  public void updateSSBO(int bindIndex, ByteBuffer data, int start, int end) {
+    if (start >= end) {
+      System.out.println("Update SSBO error: Invalid parameters.");
+      return;
+    }
+    check(nPoolUpdate(ctx, MemoryUtil.memAddress0(data), start, end));
+  }
+
+  public void getSSBO(ByteBuffer buffer) {
+    check(nPoolDownload(ctx, MemoryUtil.memAddress(buffer), buffer.remaining()));
+  }
+
+  public Shader getShaderByName(String name) {
+    for (Shader shader : shaders) {
+      if (shader.name.equals(name))
+        return shader;
+    }
+    return null;
+  }
+
+  public void printGLErrors() {
+    long s = nLastError(ctx);
+    if (s != 0) {
+      String msg = MemoryUtil.memASCII(s);
+      if (!msg.isEmpty())
+        System.out.println("HIP ERR: " + msg);
+    }
+  }
+
+  /** glGetTexImage of image 0: W*H*4 bytes, row 0 = bottom of the screen, RGBA. */
+  public void readFramebuffer(ByteBuffer rgba8) {
+    check(nReadColor(ctx, MemoryUtil.memAddress(rgba8)));
+  }
+
+  /** glGetTexImage of image 1: W*H floats. */
+  public void readDepth(ByteBuffer depth) {
+    check(nReadDepth(ctx, MemoryUtil.memAddress(depth)));
+  }
+
+  /** 16 bytes per pixel: u32 pointer, u16 rawNormal, u8 value, u8 level, u32 iter, f32 t. */
+  public void readHits(ByteBuffer hits) {
+    check(nReadHits(ctx, MemoryUtil.memAddress(hits)));
+  }
+
+  /** Dormant shader features (svotrace.comp:444, 500-504, 668-670); defaults = live behaviour. */
+  public void setPathOptions(int bounces, int mirrorMask, int spp) {
+    this.bounces = bounces;
+    this.mirrorMask = mirrorMask;
+    this.spp = spp;
+  }
+
+  private void check(int rc) {
+    if (rc != 0)
+      printGLErrors();
+  }
+
+  private static native long nCreate(int device);
+  private static native int nDestroy(long ctx);
+  private static native long nLastError(long ctx);
+  private static native int nPoolUpload(long ctx, long addr, long nbytes);
+  private static native int nPoolUpdate(long ctx, long baseAddr, long start, long end);
+  private static native int nPoolDownload(long ctx, long addr, long nbytes);
+  private static native int nSetCamera(long ctx, float px, float py, float pz, float l1x, float l1y, float l1z,
+      float l2x, float l2y, float l2z, float r1x, float r1y, float r1z, float r2x, float r2y, float r2z);
+  private static native int nSetParams(long ctx, int frameNumber, int renderMode, int bufferEnd, int useBeam,
+      int bounces, int mirrorMask, int spp);
+  private static native int nResize(long ctx, int width, int height);
+  private static native int nDispatch(long ctx);
+  private static native int nReadColor(long ctx, long addr);
+  private static native int nReadDepth(long ctx, long addr);
+  private static native int nReadHits(long ctx, long addr);
+}
