@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
   const uint32_t lane = threadIdx.x;
   const Frame &f = a.f;
   const BufPool pool = make_bufpool(a.pool, f.pool_len);
+  const uint64_t root = load_record(pool, 0u);
   const V3 cam_o = mk(f.cam[0], f.cam[1], f.cam[2]);
   const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             } else {
               d = nd;
               seg++;
-              status = trav_init(pool, t, vpos, nd, true);
+              status = trav_init(root, t, vpos, nd, true);
             }
           } else {
             const V3 sun = normalize3(mk(1.0f, 1.0f, 1.0f));
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             mask = mc;
             depth = c.t;
             seg = 1u;
-            status = trav_init(pool, t, c.voxel_pos, sun2, false);
+            status = trav_init(root, t, c.voxel_pos, sun2, false);
           } else {
             persist_emit(a, pix, px, py, sky_colour(d), 0.0f);
           }
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             value = 0u;
             depth = 0.0f;
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
-            status = trav_init(pool, t, cam_o, d, false);
+            status = trav_init(root, t, cam_o, d, false);
           }
         }
         if (base + n >= band_total) {  // this band is used up: move on (work stealing)

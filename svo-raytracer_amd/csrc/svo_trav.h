@@ -64,10 +64,11 @@ struct Trav {
   uint64_t rec;
 };
 
-enum : int { ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, ST_CAPPED = 4 };
+enum : int { ST_SKIP = -1, ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, ST_CAPPED = 4 };
 
 // set-up part of the cast (svotrace.comp:221-260)
-__device__ __forceinline__ int trav_init(const BufPool &pool, Trav &t, V3 o, V3 d, const bool cone) {
+// `root` = the root record (svotrace.comp:222), fetched once per wave by the caller
+__device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 d, const bool cone) {
   t.cone_t = cone ? 0.05f : __builtin_inff();
   t.iter = 0; t.cptr = 0; t.tag = 0; t.rec = 0; t.written = 0; t.max_depth = kMaxDepth;
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
@@ -95,7 +96,6 @@ __device__ __forceinline__ int trav_init(const BufPool &pool, Trav &t, V3 o, V3 
   if (1.5f * t.cx - t.bx > t.t_min) { t.idx ^= 1u; t.px = 1.5f; }
   if (1.5f * t.cy - t.by > t.t_min) { t.idx ^= 2u; t.py = 1.5f; }
   if (1.5f * t.cz - t.bz > t.t_min) { t.idx ^= 4u; t.pz = 1.5f; }
-  const uint64_t root = load_record(pool, 0u);
   t.pbase = rec_cp(root);
   t.pmask = rec_mask_be(root);
   return ST_ACTIVE;

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
   const uint32_t lane = threadIdx.x;
   const Frame &f = a.f;
   const BufPool pool = make_bufpool(a.pool, f.pool_len);
+  const uint64_t root = load_record(pool, 0u);
   const uint32_t total = kPrimary ? (uint32_t)f.ntiles * 64u : *a.count_in;
   const bool cone = !kPrimary && f.render_mode == 0;
   const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
             o = mk(s[S_OX * n2], s[S_OY * n2], s[S_OZ * n2]);
             d = mk(s[S_DX * n2], s[S_DY * n2], s[S_DZ * n2]);
           }
-          if (live) status = trav_init(pool, t, o, d, cone);
+          if (live) status = trav_init(root, t, o, d, cone);
         }
       }
     }

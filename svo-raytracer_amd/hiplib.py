@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvohip.so")
+LIB_PATH = os.environ.get("SVO_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvohip.so")  # SVO_HIP_LIB: A/B builds
 
 HIT_DTYPE = np.dtype([("pointer", "<u4"), ("raw_normal", "<u2"), ("value", "u1"), ("level", "u1"),
                       ("iter", "<u4"), ("t", "<f4")])
