@@ -158,3 +158,53 @@ def test_full_size_frame_properties(ctx):
     assert (ref["hits"]["pointer"][sub] == hp[sub]).all()
     assert (ref["rgba"][sub] == a["rgba"][sub]).all()
     assert (ref["depth"].view(np.uint32)[sub] == a["depth"].view(np.uint32)[sub]).all()
+
+
+# ---- BASELINE.json configs at full size: subsampled oracle + size-independent properties ----------
+
+def _check_subsampled(ctx, pool, w, h, cam, frame, mode, step, **opts):
+    import numpy as np
+    from oracle import oracle
+    res = ctx.render(pool, w, h, cam, frame, mode, **opts)
+    ref = oracle.render(pool, w, h, cam, frame, mode, xstep=step, ystep=step, **opts)
+    sub = (slice(0, h, step), slice(0, w, step))
+    assert (ref["rgba"][sub] == res["rgba"][sub]).all()
+    assert (ref["depth"].view(np.uint32)[sub] == res["depth"].view(np.uint32)[sub]).all()
+    for k in ("pointer", "value", "raw_normal", "level", "iter"):
+        assert (ref["hits"][k][sub] == res["hits"][k][sub]).all(), k
+    hp = res["hits"]["pointer"]
+    assert int(hp.max()) < pool.size and (pool[hp[hp != 0]] != 0).all()
+    return res
+
+
+@pytest.fixture(scope="module")
+def pool8192():
+    import svo_raytracer_amd.scene as scene
+    pool, st = scene.build_scene(8192)
+    assert st["depth"] == 13 and pool.size < 2**31
+    return pool
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_config3_8192_1080p_primary_plus_bounce(ctx, pool8192, pipeline):
+    """BASELINE config 3 (the metric's config): 8192^3, 1920x1080, primary + 1 diffuse bounce."""
+    from svo_raytracer_amd.cameras import CAMERAS
+    ctx.set_pipeline(pipeline)
+    a = _check_subsampled(ctx, pool8192, 1920, 1080, CAMERAS["K1"], 2, 0, 24)
+    b = ctx.render(None, None, None, None, 2, 0)
+    assert (a["rgba"] == b["rgba"]).all()   # idempotent: same frame, same bytes
+
+
+def test_config4_8192_4k_four_bounces_with_mirror(ctx, pool8192):
+    """BASELINE config 4: 3840x2160, 4 bounces incl. mirror materials (single GPU here; the
+    tile split is covered by test_row_split_equals_full_frame and the gloo test)."""
+    from svo_raytracer_amd.cameras import CAMERAS
+    ctx.set_pipeline(1)
+    _check_subsampled(ctx, pool8192, 3840, 2160, CAMERAS["K1"], 2, 0, 48, bounces=5, mirror_mask=0b1000)
+
+
+def test_config5_8192_1080p_multi_sample_accumulation(ctx, pool8192):
+    """BASELINE config 5 (reduced to 8 spp to keep the CPU oracle's share in seconds): accumulated GI."""
+    from svo_raytracer_amd.cameras import CAMERAS
+    ctx.set_pipeline(1)
+    _check_subsampled(ctx, pool8192, 1920, 1080, CAMERAS["K2"], 2, 0, 40, spp=8)
