@@ -105,6 +105,10 @@ int svo_set_rows(svo_ctx *ctx, int y0, int y1);
  * refill and in-place bounce regeneration; 2 = stage-per-kernel wavefront tracing with
  * compacted ray queues.  All three produce identical bytes. */
 int svo_set_pipeline(svo_ctx *ctx, int pipeline);
+/* pipeline-1 launch shape: persistent waves per CU (0 = fill the GPU: right for one frame at a time;
+ * about 10 when the caller keeps 2-3 frames in flight on alternating streams) and the refill round
+ * threshold in eighths (0 = default 4: a round starts once half the traversing lanes have stopped) */
+int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_eighths);
 /* record per-pixel svo_hit (costs 16 B/pixel of stores); default on */
 int svo_set_hit_records(svo_ctx *ctx, int enabled);
 
@@ -119,7 +123,9 @@ int svo_sync(svo_ctx *ctx);
 /* run the frame once more with counters on and fill svo_stats (untimed diagnostic pass) */
 int svo_count_frame(svo_ctx *ctx, svo_stats *out);
 int svo_get_stats(svo_ctx *ctx, svo_stats *out);
-/* use a caller-owned hipStream_t (e.g. torch's current stream) instead of the library's */
+/* use a caller-owned hipStream_t (e.g. torch's current stream) instead of the library's.  May be
+ * called between dispatches to alternate streams: with separate output buffers (svo_bind_outputs)
+ * two frames can then be in flight, the next one filling the GPU while the previous one drains. */
 int svo_set_stream(svo_ctx *ctx, void *hip_stream);
 /* time `iters` back-to-back frames with HIP events on the dispatch stream after `warmup`
  * untimed ones; per-frame milliseconds into ms[iters] */

@@ -24,7 +24,8 @@ class Params(ctypes.Structure):
 
 class Stats(ctypes.Structure):
     _fields_ = [("pixels", ctypes.c_uint64), ("rays", ctypes.c_uint64), ("nan_rays", ctypes.c_uint64),
-                ("iterations", ctypes.c_uint64), ("alg_bytes", ctypes.c_uint64), ("max_iter", ctypes.c_uint64)]
+                ("iterations", ctypes.c_uint64), ("alg_bytes", ctypes.c_uint64), ("max_iter", ctypes.c_uint64), ("descends", ctypes.c_uint64),
+                ("advances", ctypes.c_uint64), ("pops", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -64,6 +64,7 @@ typedef struct svo_oracle_stats {
   uint64_t iterations; /* loop iterations of counted rays */
   uint64_t alg_bytes;  /* 7 per cast (root record) + size of every fetched child record */
   uint64_t max_iter;   /* largest iteration count of a counted ray */
+  uint64_t descends, advances, pops; /* iteration mix of counted rays (diagnostic) */
 } svo_oracle_stats;
 
 typedef struct { float x, y, z; } vec3;
@@ -322,6 +323,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
           octstack[scale].tmax = t_max;
         }
         h = tc_max;
+        if (!is_nan_ray) c->st->descends++;
         parent = child;
         idx = 0u;
         --scale;
@@ -335,6 +337,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
       }
     }
     /* ADVANCE */
+    if (!is_nan_ray) c->st->advances++;
     uint32_t step_mask = 0u;
     if (tx_corner <= tc_max) { step_mask ^= 1u; pos.x -= scale_exp2; }
     if (ty_corner <= tc_max) { step_mask ^= 2u; pos.y -= scale_exp2; }
@@ -343,6 +346,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
     idx ^= step_mask;
     /* POP */
     if ((idx & step_mask) != 0) {
+      if (!is_nan_ray) c->st->pops++;
       uint32_t differing_bits = 0;
       if (step_mask & 1u) differing_bits |= f2u(pos.x) ^ f2u(pos.x + scale_exp2);
       if (step_mask & 2u) differing_bits |= f2u(pos.y) ^ f2u(pos.y + scale_exp2);

@@ -271,6 +271,14 @@ int svo_set_pipeline(svo_ctx *c, int pipeline) {
   return SVO_OK;
 }
 
+int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_eighths) {
+  if (!c || waves_per_cu < 0 || round_threshold_eighths < 0 || round_threshold_eighths > 7)
+    return fail(c, SVO_E_INVALID, "svo_set_tuning: bad values");
+  c->pb.waves_per_cu = waves_per_cu;
+  c->pb.thresh_num = round_threshold_eighths ? round_threshold_eighths : 4;
+  return SVO_OK;
+}
+
 int svo_set_hit_records(svo_ctx *c, int enabled) {
   if (!c) return SVO_E_INVALID;
   c->write_hits = enabled ? 1 : 0;
@@ -280,8 +288,12 @@ int svo_set_hit_records(svo_ctx *c, int enabled) {
 int svo_set_stream(svo_ctx *c, void *hip_stream) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->own_stream && c->stream) HIPCHK(c, hipStreamDestroy(c->stream));
+  // no synchronisation here: a caller may alternate streams to keep two frames in flight
+  // (different output buffers); ordering between streams is the caller's business
+  if (c->own_stream && c->stream) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamDestroy(c->stream));
+  }
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
   return SVO_OK;

@@ -229,7 +229,11 @@ struct PersistBuffers {
   size_t npix = 0;
   int blocks = 0;
   int thresh_num = 4;
+  int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
+  int max_per_cu = 16, cus = 256;
+  unsigned launches = 0;
 };
+constexpr int kHeadSets = 8;
 
 inline void persist_free(PersistBuffers &b) {
   if (b.heads) (void)hipFree(b.heads);
@@ -258,16 +262,21 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   const size_t npix = (size_t)f.width * (size_t)f.height;
   hipError_t e;
   if (!b.heads) {
-    if ((e = hipMalloc((void **)&b.heads, 64 * sizeof(uint32_t))) != hipSuccess) return (int)e;
+    if ((e = hipMalloc((void **)&b.heads, kHeadSets * 64 * sizeof(uint32_t))) != hipSuccess) return (int)e;
     int dev = 0, cus = 256, per_cu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel<0>, 64, 0) != hipSuccess || per_cu < 1)
       per_cu = 16;
-    // tuning knobs (defaults are the shipped values)
-    if (const char *e1 = getenv("SVO_PERSIST_WAVES_PER_CU")) per_cu = atoi(e1) > 0 ? atoi(e1) : per_cu;
+    b.max_per_cu = per_cu;
+    b.cus = cus;
+    // experiment knobs (override svo_set_tuning)
+    if (const char *e1 = getenv("SVO_PERSIST_WAVES_PER_CU")) b.waves_per_cu = atoi(e1);
     if (const char *e2 = getenv("SVO_PERSIST_THRESH")) b.thresh_num = atoi(e2);
-    b.blocks = cus * per_cu;
+  }
+  {
+    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : b.max_per_cu;
+    b.blocks = b.cus * per_cu;
   }
   const int spp = f.spp < 1 ? 1 : f.spp;
   if (spp > 1 && b.npix != npix) {
@@ -278,12 +287,13 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   }
   PersistArgs a;
   a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = b.facc; a.npix = npix;
-  a.heads = b.heads;
   a.tiles_per_band = (f.ntiles + 7) / 8;
   a.thresh_num = b.thresh_num;
   const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
   for (int s = 0; s < spp; s++) {
-    if ((e = hipMemsetAsync(b.heads, 0, 64 * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
+    // a ring of counter sets: frames may be in flight on different streams at the same time
+    a.heads = b.heads + (size_t)(b.launches++ % kHeadSets) * 64;
+    if ((e = hipMemsetAsync(a.heads, 0, 64 * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
     switch (f.render_mode) {
       case 0: persist_launch_mode<0>(a, blocks, stream); break;
