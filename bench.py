@@ -116,7 +116,9 @@ def main():
     nbuf = max(2 if use_comm else 1, args.inflight)  # frame k drains / is gathered while frame k+1 is traced
     color = [torch.zeros((hp, W), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
     depth = [torch.zeros((hp, W), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-    hits = torch.zeros((hp, W, 4), dtype=torch.int32, device="cuda") if args.hits else None
+    hits = [torch.zeros((hp, W, 4), dtype=torch.int32, device="cuda") for _ in range(nbuf)] if args.hits else None
+    scratch_c = torch.zeros((rows_per_rank, W), dtype=torch.int32, device="cuda") if use_comm and rank == 0 else None
+    scratch_d = torch.zeros((rows_per_rank, W), dtype=torch.float32, device="cuda") if use_comm and rank == 0 else None
     ctx.set_hit_records(bool(args.hits))
     ctx.set_rows(y0, y1)
     main_stream = torch.cuda.current_stream()
@@ -137,7 +139,7 @@ def main():
         ctx.set_stream(stream.cuda_stream)
         if gathered[b] is not None:
             stream.wait_event(gathered[b])
-        ctx.bind_outputs(color[b].data_ptr(), depth[b].data_ptr(), hits.data_ptr() if hits is not None else None)
+        ctx.bind_outputs(color[b].data_ptr(), depth[b].data_ptr(), hits[b].data_ptr() if hits is not None else None)
         if state["timing"]:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -152,18 +154,18 @@ def main():
             done.record(stream)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(done)
-                gather_bands_to_root(dist, color[b], rank, world, rows_per_rank, force=force_comm)
-                gather_bands_to_root(dist, depth[b], rank, world, rows_per_rank, force=force_comm)
+                gather_bands_to_root(dist, color[b], rank, world, rows_per_rank, force=force_comm, scratch=scratch_c)
+                gather_bands_to_root(dist, depth[b], rank, world, rows_per_rank, force=force_comm, scratch=scratch_d)
                 ev = torch.cuda.Event()
                 ev.record(comm_stream)
                 gathered[b] = ev
 
-    ctx.bind_outputs(color[0].data_ptr(), depth[0].data_ptr(), hits.data_ptr() if hits is not None else None)
+    ctx.bind_outputs(color[0].data_ptr(), depth[0].data_ptr(), hits[0].data_ptr() if hits is not None else None)
 
     def drain():
         torch.cuda.synchronize()
         ctx.set_stream(main_stream.cuda_stream)
-        ctx.bind_outputs(color[0].data_ptr(), depth[0].data_ptr(), hits.data_ptr() if hits is not None else None)
+        ctx.bind_outputs(color[0].data_ptr(), depth[0].data_ptr(), hits[0].data_ptr() if hits is not None else None)
 
     # ---- ray count of the frame (untimed counting pass; identical image) -------------------
     cstats = ctx.count_frame()

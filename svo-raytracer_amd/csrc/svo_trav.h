@@ -186,6 +186,14 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
 __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, const uint32_t lane, Trav &t) {
   t.iter++;
   if (t.iter > kMaxIter) return ST_CAPPED;
+#ifdef SVO_DUMMY_VALU
+  {  // experiment: extra dependent-free VALU work to test whether the loop is issue-bound
+    float x = t.h;
+#pragma unroll
+    for (int i = 0; i < SVO_DUMMY_VALU; i++) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
+    asm volatile("" ::"v"(x));
+  }
+#endif
   if (t.t_min > t.cone_t) t.max_depth = 11;
   const float tcx = t.px * t.cx - t.bx;
   const float tcy = t.py * t.cy - t.by;
@@ -193,7 +201,22 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
   const float tc_max = vmin3(tcx, tcy, tcz);
   const uint32_t cs = t.idx ^ t.octant;
   t.tag = (t.pmask >> (2u * cs)) & 3u;
+#ifdef SVO_DIET2
+  {
+    // 7c - 2*(2*popc(lo) + popc(lo & hi)) with v_bcnt's accumulate operand
+    const uint32_t below = ~(~0u << (2u * cs));
+    const uint32_t lo = t.pmask & 0x5555u & below;
+    const uint32_t both = lo & (t.pmask >> 1);
+    uint32_t acc, base7;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc) : "v"(lo));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"(lo), "v"(acc));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"(both), "v"(acc));
+    asm("v_mad_u32_u24 %0, %1, 7, %2" : "=v"(base7) : "v"(cs), "v"(t.pbase));
+    asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(t.cptr) : "v"(acc), "v"(base7));
+  }
+#else
   t.cptr = t.pbase + child_offset(t.pmask, cs);
+#endif
   t.rec = load_record(pool, t.cptr);
   if (rec_value(t.rec) != 0u && t.t_min <= t.t_max) {
     if (kMaxScale - t.scale == t.max_depth) return ST_HIT;

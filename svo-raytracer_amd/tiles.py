@@ -26,7 +26,7 @@ def gather_bands(dist, full, rank, rows_per_rank):
     return full
 
 
-def gather_bands_to_root(dist, full, rank, world, rows_per_rank, dst=0, force=False):
+def gather_bands_to_root(dist, full, rank, world, rows_per_rank, dst=0, force=False, scratch=None):
     """Gather the equal-sized bands to rank `dst` only (the north-star exchange step: one
     frame owner, every peer sends its band over its direct xGMI link).  `full` is
     [rows_per_rank * world, W, ...] on every rank; only dst's copy ends up complete."""
@@ -36,7 +36,7 @@ def gather_bands_to_root(dist, full, rank, world, rows_per_rank, dst=0, force=Fa
     if rank == dst:
         parts = [full[r * rows_per_rank:(r + 1) * rows_per_rank] for r in range(world)]
         # the root's own band is already in place; give gather a scratch slot for it
-        parts[dst] = mine.clone()
+        parts[dst] = scratch if scratch is not None else mine.clone()
         dist.gather(mine, gather_list=parts, dst=dst)
     else:
         dist.gather(mine, gather_list=None, dst=dst)
