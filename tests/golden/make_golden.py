@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import svo_raytracer_amd.scene as scene  # noqa: E402
 import poolbuilder  # noqa: E402
+from svo_raytracer_amd import hostlib  # noqa: E402
 
 SHADER = "/root/reference/src/shaders/svotrace.comp"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
@@ -53,6 +54,20 @@ K1 = rot_cam((1.5, 1.42, 1.5), -0.5, 0.3)          # inside the cube, pitched to
 K2 = rot_cam((1.2, 1.40, 1.8), -0.08, 0.7)         # grazing view, long rays
 KOUT = rot_cam((1.45, 1.7, 2.9), -0.35, 0.1)       # outside the cube: world faces -> zero / NaN normals (Q3, Q4)
 KDUST = rot_cam((1.3, 1.06, 1.3), -1.2, 0.2)       # looking down at the floor of the dust scene
+KEDIT = rot_cam((1.5, 1.62, 1.55), -1.15, 0.4)     # looking down at the SDF-edited area of the 64^3 world
+
+
+def edited_pool(base):
+    """A pool after SDF brush edits through the C++ mirror of Octree.useSDFBrush (Octree.java:700-885):
+    re-tagged interior nodes that keep stale child-pointer / mask bytes (quirk Q5), DELETE_VALUE (127)
+    orphans, appended subtrees with SDF normals."""
+    o = hostlib.Octree(4096)
+    o.adopt(base)
+    o.useSDFBrushSphere((20, 24, 40), 7, 2, worldSize=64, maxLOD=6)      # add material 2
+    o.useSDFBrushSphere((44, 19, 24), 6, 0, worldSize=64, maxLOD=6)      # carve
+    o.useSDFBrushBox((34, 26, 30), 3, 5, 4, 3, worldSize=64, maxLOD=6)   # Main.java:246-248 style box
+    o.useSDFBrushSphere((30, 21, 30), 9, 1, worldSize=64, maxLOD=6)      # big fill: whole sub-trees become tag 2
+    return o.getByteBuffer()
 
 
 def cases():
@@ -68,6 +83,7 @@ def cases():
         # floor + lattice of isolated voxels: shadow rays with > 260 iterations (penumbra branch,
         # svotrace.comp:616-619) and packed-555 normals (quirk Q4 / Q7: NaN rays, iter 1501)
         "dust256": poolbuilder.pool_from_grid(poolbuilder.dust_grid(256, floor=10, cell=8))[0],
+        "s64sdf": edited_pool(s64),
     }
     c = []
     for m in (0, 1, 2, 3):
@@ -90,6 +106,9 @@ def cases():
     for m in (0, 1, 2, 3):
         c.append(("dust256_KDUST_m%d" % m, "dust256", 64, 48, KDUST, 2, m))
     c.append(("dust256_K1_m2", "dust256", 96, 64, K1, 2, 2))
+    for m in (0, 1, 2, 3):
+        c.append(("s64sdf_KEDIT_m%d" % m, "s64sdf", 96, 64, KEDIT, 2, m))
+    c.append(("s64sdf_K0_m2", "s64sdf", 96, 64, K0, 2, 2))
     return pools, c
 
 
