@@ -8,8 +8,8 @@ Rays = intersectOctree-equivalent casts actually performed (counted by an untime
 counting pass of the same frame); value = rays of all ranks / wall time of K steps.
 
 N > 1 (one process per GPU, launched by torch.distributed.run).  The path shards by
-screen tile: the pool is replicated by one RCCL broadcast, every rank renders one band
-of 8-pixel tile rows, and each step's bands are gathered to rank 0 over xGMI (RCCL
+screen tile: the pool is replicated by one RCCL broadcast, every rank renders every
+N-th 8-pixel tile row (interleaved stripes, packed into one band of the gather buffer), and each step's bands are gathered to rank 0 over xGMI (RCCL
 gather = one direct send per peer), overlapped with the next frame's traversal on a
 second stream.  Default --scaling weak: the per-GPU band stays 1920x1080 and the frame
 grows to 1920 x (1080*N) rows (same camera, denser rows), so per-GPU work is fixed.
@@ -53,6 +53,8 @@ def parse():
                          "previous one drains its longest paths")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle sample time (0 = skip)")
     ap.add_argument("--hits", type=int, default=0, help="also store 16-byte hit records per pixel")
+    ap.add_argument("--deinterleave", type=int, default=0,
+                    help="rank 0 also reorders the gathered stripe-major tile buffers into frame order each step")
     return ap.parse_args()
 
 
@@ -75,7 +77,7 @@ def main():
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
     from svo_raytracer_amd.cameras import CAMERAS
-    from svo_raytracer_amd.tiles import band_rows, gather_bands_to_root
+    from svo_raytracer_amd.tiles import stripe_layout, gather_bands_to_root, deinterleave
 
     W, H = args.width, args.height
     cam = CAMERAS[args.camera]
@@ -111,7 +113,9 @@ def main():
     ctx.set_pipeline(args.pipeline)
     if args.pipeline == 1 and max(2 if use_comm else 1, args.inflight) > 1:
         ctx.set_tuning(10, 0)  # several frames in flight share the CUs: 10 persistent waves per CU and frame
-    y0, y1, rows_per_rank = band_rows(H_total, world, rank)
+    # rank r renders tile rows r, r + N, r + 2N, ... (interleaved: every rank sees the same mix of near and
+    # far terrain) and stores them packed in its band of the gather buffer
+    s_first, s_step, s_n, s_out0, rows_per_rank = stripe_layout(H_total, world, rank)
     hp = rows_per_rank * world  # padded height so that every rank's band has the same size
     nbuf = max(2 if use_comm else 1, args.inflight)  # frame k drains / is gathered while frame k+1 is traced
     color = [torch.zeros((hp, W), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
@@ -120,7 +124,7 @@ def main():
     scratch_c = torch.zeros((rows_per_rank, W), dtype=torch.int32, device="cuda") if use_comm and rank == 0 else None
     scratch_d = torch.zeros((rows_per_rank, W), dtype=torch.float32, device="cuda") if use_comm and rank == 0 else None
     ctx.set_hit_records(bool(args.hits))
-    ctx.set_rows(y0, y1)
+    ctx.set_stripes(s_first, s_step, s_n, s_out0)
     main_stream = torch.cuda.current_stream()
     streams = [main_stream] + [torch.cuda.Stream() for _ in range(nbuf - 1)]
     for st_ in streams[1:]:
@@ -156,6 +160,10 @@ def main():
                 comm_stream.wait_event(done)
                 gather_bands_to_root(dist, color[b], rank, world, rows_per_rank, force=force_comm, scratch=scratch_c)
                 gather_bands_to_root(dist, depth[b], rank, world, rows_per_rank, force=force_comm, scratch=scratch_d)
+                if rank == 0 and args.deinterleave:  # stripe-major as gathered -> frame order, on the frame owner
+                    frame_c = deinterleave(color[b], world, rows_per_rank, H_total)
+                    frame_d = deinterleave(depth[b], world, rows_per_rank, H_total)
+                    state["frame"] = (frame_c, frame_d)
                 ev = torch.cuda.Event()
                 ev.record(comm_stream)
                 gathered[b] = ev
@@ -227,7 +235,7 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "%d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), camera %s, "
-                            "pipeline %d, one %dx%d tile-row band per GPU, %d GPU(s), bands gathered to rank 0" % (
+                            "pipeline %d, %dx%d pixels of interleaved tile rows per GPU, %d GPU(s), gathered to rank 0" % (
                                 args.size, nbytes, W, H_total, args.mode,
                                 "primary + %d bounce" % (args.bounces - 1) if args.mode == 0 else "primary + shadow ray",
                                 args.camera, args.pipeline, W, rows_per_rank, world),

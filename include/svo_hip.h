@@ -101,6 +101,10 @@ int svo_resize(svo_ctx *ctx, int width, int height);
  * the last); default = whole frame; svo_resize to a different size resets it.  No reference
  * equivalent (single GPU). */
 int svo_set_rows(svo_ctx *ctx, int y0, int y1);
+/* interleaved variant for load balance: render tile rows first + j*step, j = 0..n-1 (8 pixel rows each,
+ * rows past the image height are skipped) and store them PACKED: tile row j lands at output rows
+ * out_row0 + 8j .. out_row0 + 8j + 7.  Rank r of N uses (r, N, ceil((tile_rows - r) / N), r * band_rows). */
+int svo_set_stripes(svo_ctx *ctx, int first_tile_row, int tile_row_step, int n_tile_rows, int out_row0);
 /* 0 = one thread per pixel (the reference's decomposition); 1 = persistent waves with lane
  * refill and in-place bounce regeneration; 2 = stage-per-kernel wavefront tracing with
  * compacted ray queues.  All three produce identical bytes. */

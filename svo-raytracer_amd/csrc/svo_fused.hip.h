@@ -153,10 +153,10 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
   return (b & 7) * per + (b >> 3);
 }
 
-__device__ __forceinline__ void store_pixel(const Frame &f, int px, int py, V3 fin, float depth, const PathState &ps,
-                                            uint32_t *color, float *depthbuf, uint4 *hits) {
+__device__ __forceinline__ void store_pixel(const Frame &f, int px, int py, int oy, V3 fin, float depth,
+                                            const PathState &ps, uint32_t *color, float *depthbuf, uint4 *hits) {
   if (px < 10 && py < 10) fin = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
-  const size_t o = (size_t)py * (size_t)f.width + (size_t)px;
+  const size_t o = (size_t)oy * (size_t)f.width + (size_t)px;
   color[o] = unorm8(fin.x) | (unorm8(fin.y) << 8) | (unorm8(fin.z) << 16) | 0xff000000u;
   depthbuf[o] = depth;
   if (f.write_hits) {
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(64) void trace_fused_kernel(const uint8_t *__restri
   const uint32_t lane = threadIdx.x;
   const int tx = tile % f.tiles_x, ty = tile / f.tiles_x;
   const int px = tx * 8 + (int)(lane & 7u);
-  const int py = f.y0 + ty * 8 + (int)(lane >> 3);
+  const int py = frame_gy(f, ty, (int)(lane >> 3));
+  const int oy = frame_oy(f, ty, (int)(lane >> 3));
   Counters cnt = {0, 0, 0, 0, 0};
   const bool live = px < f.width && py < f.y1 && py < f.height;
   if (live) {
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(64) void trace_fused_kernel(const uint8_t *__restri
       const float inv = 1.0f / (float)spp;
       fin = mk(fin.x * inv, fin.y * inv, fin.z * inv);
     }
-    store_pixel(f, px, py, fin, depth, ps, color, depthbuf, hits);
+    store_pixel(f, px, py, oy, fin, depth, ps, color, depthbuf, hits);
   }
   if (kCount) {
     // wave-level reduction, one atomic per counter per wave

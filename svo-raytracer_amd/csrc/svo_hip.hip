@@ -31,6 +31,7 @@ struct svo_ctx {
   float cam[15] = {1.5f, 1.5f, 2.0f, -1.6f, -0.9f, -1.f, -1.6f, 0.9f, -1.f, 1.6f, -0.9f, -1.f, 1.6f, 0.9f, -1.f};
   int width = 0, height = 0, y0 = 0, y1 = 0;
   bool rows_set = false;
+  int row_step = 1, out_y0 = 0, n_tile_rows = -1;  // stripe mode (svo_set_stripes); n_tile_rows < 0 = band mode
   int frame_number = 2, render_mode = 2, buffer_end = 0, use_beam = 0, bounces = 2, spp = 1;
   uint32_t mirror_mask = 0;
   int pipeline = 0;
@@ -242,6 +243,7 @@ int svo_resize(svo_ctx *c, int width, int height) {
   if (!c->external_outputs) { c->d_color = c->own_color; c->d_depth = c->own_depth; c->d_hits = c->own_hits; }
   c->width = width; c->height = height;
   c->y0 = 0; c->y1 = height; c->rows_set = false;  // a new image size resets the row band to the whole frame
+  c->row_step = 1; c->out_y0 = 0; c->n_tile_rows = -1;
   return SVO_OK;
 }
 
@@ -262,6 +264,16 @@ int svo_set_rows(svo_ctx *c, int y0, int y1) {
   if (!c) return SVO_E_INVALID;
   if (y0 < 0 || y1 < y0 || (y0 & 7)) return fail(c, SVO_E_INVALID, "svo_set_rows: need 0 <= y0 <= y1, y0 % 8 == 0");
   c->y0 = y0; c->y1 = y1; c->rows_set = true;
+  c->row_step = 1; c->out_y0 = y0; c->n_tile_rows = -1;
+  return SVO_OK;
+}
+
+int svo_set_stripes(svo_ctx *c, int first_tile_row, int tile_row_step, int n_tile_rows, int out_row0) {
+  if (!c) return SVO_E_INVALID;
+  if (first_tile_row < 0 || tile_row_step < 1 || n_tile_rows < 0 || out_row0 < 0)
+    return fail(c, SVO_E_INVALID, "svo_set_stripes: bad values");
+  c->y0 = first_tile_row * 8; c->y1 = 0x7fffffff; c->rows_set = true;
+  c->row_step = tile_row_step; c->out_y0 = out_row0; c->n_tile_rows = n_tile_rows;
   return SVO_OK;
 }
 
@@ -307,12 +319,14 @@ static int make_frame(svo_ctx *c, Frame &f) {
   f.width = c->width; f.height = c->height;
   f.y0 = std::min(c->y0, c->height);
   f.y1 = std::min(c->y1, c->height);
+  f.row_step = c->row_step;
+  f.out_y0 = c->n_tile_rows < 0 ? f.y0 : c->out_y0;
   f.frame_number = c->frame_number; f.render_mode = c->render_mode;
   f.bounces = c->bounces; f.spp = c->spp; f.mirror_mask = c->mirror_mask;
   f.pool_len = (uint32_t)c->pool_len;
   f.dword0 = c->dword0;
   f.tiles_x = (c->width + 7) / 8;
-  f.tiles_y = (f.y1 - f.y0 + 7) / 8;
+  f.tiles_y = c->n_tile_rows < 0 ? (f.y1 - f.y0 + 7) / 8 : c->n_tile_rows;
   f.ntiles = f.tiles_x * f.tiles_y;
   f.write_hits = (c->write_hits && c->d_hits) ? 1 : 0;
   return SVO_OK;

@@ -9,7 +9,9 @@ namespace svo {
 struct Frame {
   float cam[15];        // pos, l1, l2, r1, r2
   int32_t width, height;
-  int32_t y0, y1;       // pixel rows [y0, y1) rendered by this launch
+  int32_t y0, y1;       // first pixel row of this launch's first tile row; rows >= y1 are not rendered
+  int32_t row_step;     // distance, in tile rows, between consecutive tile rows of this launch (1 = a band)
+  int32_t out_y0;       // output row of the launch's first tile row (outputs of a launch are packed)
   int32_t frame_number, render_mode;
   int32_t bounces, spp;
   uint32_t mirror_mask;
@@ -24,5 +26,15 @@ struct DeviceCounters {
   unsigned long long pixels, rays, nan_rays, iterations, alg_bytes;
   unsigned int max_iter, pad;
 };
+
+// tile row `ty` of the launch, row `ly` inside the tile -> pixel row in the frame / row in the output images
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int frame_gy(const Frame &f, int ty, int ly) { return f.y0 + ty * 8 * f.row_step + ly; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int frame_oy(const Frame &f, int ty, int ly) { return f.out_y0 + ty * 8 + ly; }
 
 }  // namespace svo

@@ -187,9 +187,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
           const int tile = first_tile + (int)(slot >> 6);
           const uint32_t l = slot & 63u;
           px = (tile % f.tiles_x) * 8 + (int)(l & 7u);
-          py = f.y0 + (tile / f.tiles_x) * 8 + (int)(l >> 3);
+          py = frame_gy(f, tile / f.tiles_x, (int)(l >> 3));
           if (px < f.width && py < f.y1 && py < f.height) {
-            pix = (uint32_t)py * (uint32_t)f.width + (uint32_t)px;
+            pix = (uint32_t)frame_oy(f, tile / f.tiles_x, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
             d = primary_direction(f, px, py);
             seg = 0u;
             mask = mk(1.f, 1.f, 1.f);
@@ -248,9 +248,9 @@ inline void persist_launch_mode(const PersistArgs &a, int blocks, hipStream_t st
 
 __global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t npix, uint32_t *color) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = f.y0 + blockIdx.y;
+  const int y = frame_gy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7);
   if (x >= f.width || y >= f.y1 || y >= f.height) return;
-  const size_t pix = (size_t)y * f.width + x;
+  const size_t pix = (size_t)frame_oy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7) * f.width + x;
   const float inv = 1.0f / (float)f.spp;
   V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
   if (x < 10 && y < 10) col = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
@@ -305,7 +305,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   }
   if (spp > 1) {
-    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.y1 - f.y0));
+    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8));
     hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, b.facc, npix, color);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   }

@@ -256,15 +256,18 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
             const int tile = (int)(slot >> 6);
             const uint32_t l = slot & 63u;
             px = (tile % f.tiles_x) * 8 + (int)(l & 7u);
-            py = f.y0 + (tile / f.tiles_x) * 8 + (int)(l >> 3);
+            py = frame_gy(f, tile / f.tiles_x, (int)(l >> 3));
             live = px < f.width && py < f.y1 && py < f.height;
-            pix = (uint32_t)py * (uint32_t)f.width + (uint32_t)px;
+            pix = (uint32_t)frame_oy(f, tile / f.tiles_x, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
             o = mk(f.cam[0], f.cam[1], f.cam[2]);
             d = live ? primary_direction(f, px, py) : mk(0.f, 0.f, 1.f);
           } else {
             pix = a.queue_in[slot];
             px = (int)(pix % (uint32_t)f.width);
-            py = (int)(pix / (uint32_t)f.width);
+            {
+              const int oyl = (int)(pix / (uint32_t)f.width) - f.out_y0;
+              py = frame_gy(f, oyl >> 3, oyl & 7);
+            }
             const float *s = a.state + pix;
             const size_t n2 = a.npix;
             o = mk(s[S_OX * n2], s[S_OY * n2], s[S_OZ * n2]);
@@ -291,9 +294,9 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
 // spp > 1: colour sums -> rgba8
 __global__ void resolve_kernel(const Frame f, const float *facc, size_t npix, uint32_t *color) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = f.y0 + blockIdx.y;
+  const int y = frame_gy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7);
   if (x >= f.width || y >= f.y1 || y >= f.height) return;
-  const size_t pix = (size_t)y * f.width + x;
+  const size_t pix = (size_t)frame_oy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7) * f.width + x;
   const float inv = 1.0f / (float)f.spp;
   V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
   if (x < 10 && y < 10) col = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
@@ -358,7 +361,7 @@ inline int wavefront_launch(WavefrontBuffers &b, const uint8_t *pool, const Fram
     }
   }
   if (spp > 1) {
-    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.y1 - f.y0));
+    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8));
     hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, stream, f, b.facc, b.npix, color);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -14,7 +14,7 @@ HIT_DTYPE = np.dtype([("pointer", "<u4"), ("raw_normal", "<u2"), ("value", "u1")
 
 EXPORTS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
-    "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows",
+    "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits",
     "svo_output_device_ptrs",
@@ -57,6 +57,7 @@ def lib():
         L.svo_set_params.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.c_uint32, ci]
         L.svo_resize.argtypes = [vp, ci, ci]
         L.svo_set_rows.argtypes = [vp, ci, ci]
+        L.svo_set_stripes.argtypes = [vp, ci, ci, ci, ci]
         L.svo_set_pipeline.argtypes = [vp, ci]
         L.svo_set_hit_records.argtypes = [vp, ci]
         L.svo_set_tuning.argtypes = [vp, ci, ci]
@@ -156,6 +157,9 @@ class HipContext:
 
     def set_rows(self, y0, y1):
         self._chk(self._L.svo_set_rows(self._h, int(y0), int(y1)))
+
+    def set_stripes(self, first_tile_row, tile_row_step, n_tile_rows, out_row0):
+        self._chk(self._L.svo_set_stripes(self._h, int(first_tile_row), int(tile_row_step), int(n_tile_rows), int(out_row0)))
 
     def set_pipeline(self, p):
         self._chk(self._L.svo_set_pipeline(self._h, int(p)))

@@ -41,3 +41,24 @@ def gather_bands_to_root(dist, full, rank, world, rows_per_rank, dst=0, force=Fa
     else:
         dist.gather(mine, gather_list=None, dst=dst)
     return full
+
+
+def stripe_layout(height, world, rank):
+    """Interleaved sharding for load balance: rank r renders tile rows r, r + world, r + 2*world, ...
+    Returns (first_tile_row, tile_row_step, n_tile_rows, out_row0, rows_per_rank): the arguments of
+    svo_set_stripes plus the padded band size every rank's packed stripes occupy in the gather buffer."""
+    tile_rows = (height + TILE - 1) // TILE
+    per = (tile_rows + world - 1) // world
+    n = max(0, (tile_rows - rank + world - 1) // world)
+    rows_per_rank = per * TILE
+    return rank, world, n, rank * rows_per_rank, rows_per_rank
+
+
+def deinterleave(full, world, rows_per_rank, height):
+    """[world * rows_per_rank, W, ...] stripe-major (as gathered) -> [height, W, ...] in frame order."""
+    per = rows_per_rank // TILE
+    shp = full.shape
+    v = full.reshape(world, per, TILE, *shp[1:])
+    perm = (1, 0, 2) + tuple(range(3, v.dim() if hasattr(v, "dim") else v.ndim))
+    v = v.permute(*perm) if hasattr(v, "permute") else v.transpose(perm)
+    return v.reshape(per * world * TILE, *shp[1:])[:height]

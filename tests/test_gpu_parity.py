@@ -109,6 +109,36 @@ def test_row_split_equals_full_frame(ctx):
     assert (parts == full["rgba"]).all()
 
 
+@pytest.mark.parametrize("pipeline", PIPELINES)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_interleaved_stripes_reassemble_the_frame(ctx, pipeline, world):
+    """Load-balanced sharding: rank r renders tile rows r, r+N, ... packed into its band of the gather buffer."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd.cameras import CAMERAS
+    from svo_raytracer_amd.tiles import stripe_layout, deinterleave
+    pool, _ = scene.build_scene(256)
+    w, h = 200, 116                      # 15 tile rows, the last one partial
+    ctx.set_pipeline(pipeline)
+    full = ctx.render(pool, w, h, CAMERAS["K1"], 2, 0)
+    rpr = stripe_layout(h, world, 0)[4]
+    import torch
+    col = torch.zeros((rpr * world, w), dtype=torch.int32, device="cuda")
+    dep = torch.zeros((rpr * world, w), dtype=torch.float32, device="cuda")
+    ctx.resize(w, h)
+    ctx.bind_outputs(col.data_ptr(), dep.data_ptr(), None)
+    for r in range(world):
+        first, step, n, out0, rows = stripe_layout(h, world, r)
+        ctx.set_stripes(first, step, n, out0)
+        ctx.dispatch()
+    torch.cuda.synchronize()
+    ctx.bind_outputs(None, None, None)
+    ctx.set_rows(0, h)
+    got = deinterleave(col.cpu().numpy().view(np.uint8).reshape(rpr * world, w, 4), world, rpr, h)
+    gotd = deinterleave(dep.cpu().numpy(), world, rpr, h)
+    assert (got == full["rgba"]).all()
+    assert (gotd.view(np.uint32) == full["depth"].view(np.uint32)).all()
+
+
 def test_pool_update_and_errors(ctx):
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
