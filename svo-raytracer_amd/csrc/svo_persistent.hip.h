@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 
     // ---------------- traverse until enough lanes have stopped to make a round worthwhile
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
+    // (a fixed "N lanes free" trigger was tried instead of the proportional one: 3 % slower at its best setting)
     const int threshold = bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0;
     for (;;) {
       if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t);
