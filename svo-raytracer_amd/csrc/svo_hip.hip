@@ -450,4 +450,15 @@ int svo_output_device_ptrs(svo_ctx *c, void **color, void **depth, void **hits) 
   return SVO_OK;
 }
 
+#ifdef SVO_STAMPS
+// diagnostic builds only: raw copy of the persistent pipeline's counter ring (8 sets x 256 B)
+int svo_debug_heads(svo_ctx *c, void *out) {
+  if (!c || !out || !c->pb.heads) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(out, c->pb.heads + (size_t)((c->pb.launches - 1) % kHeadSets) * kHeadWords + 8 * kHeadStride, 128, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+#endif
+
 }  // extern "C"

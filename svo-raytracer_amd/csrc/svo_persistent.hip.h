@@ -23,6 +23,13 @@
 
 namespace svo {
 
+// One 128-byte line per band counter.  With the 8 counters in one line every refill atomic of every CU
+// serialised on it and -- vmcnt being in-order on gfx950 -- stalled the record load behind it: in-kernel
+// stamps (SVO_STAMPS build) showed the load wait growing from 420 to 2000 cycles per iteration as rounds
+// became more frequent; with separate lines it stays below 500.
+constexpr int kHeadStride = 32;
+constexpr int kHeadWords = 8 * kHeadStride + 32;  // + diagnostics words
+
 struct PersistArgs {
   const uint8_t *pool;
   Frame f;
@@ -44,6 +51,10 @@ __device__ __forceinline__ uint32_t xcc_id() {
 }
 
 __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix, int px, int py, V3 col, float depth) {
+#ifdef SVO_NO_STORES  // timing experiment only: keep the values alive, skip the stores
+  asm volatile("" ::"v"(col.x), "v"(col.y), "v"(col.z), "v"(depth), "v"(pix));
+  return;
+#endif
   if (a.f.spp <= 1) {
     if (px < 10 && py < 10) col = a.f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
     a.color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
@@ -80,6 +91,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
   uint32_t band = xcc_id();
   int bands_left = 8;
 
+#ifdef SVO_STAMPS
+  unsigned long long st_round = 0, st_trav = 0, st_nround = 0, st_ntrip = 0, st_shade = 0, st_load = 0, st_t0 = __builtin_readcyclecounter();
+#endif
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
     if (status >= ST_HIT) {
@@ -168,6 +182,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
       }
     }
 
+#ifdef SVO_STAMPS
+    st_shade += __builtin_readcyclecounter() - st_t0;
+#endif
     // ---------------- refill idle lanes: ballot + prefix count, one atomic per wave
     if (bands_left > 0) {
       const unsigned long long idle = __ballot(status == ST_IDLE);
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         band_tiles = band_tiles < 0 ? 0 : (band_tiles > a.tiles_per_band ? a.tiles_per_band : band_tiles);
         const uint32_t band_total = (uint32_t)band_tiles * 64u;
         uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(a.heads + band, n);
+        if ((int)lane == leader) base = atomicAdd(a.heads + band * kHeadStride, n);
         base = (uint32_t)__shfl((int)base, leader);
         const uint32_t slot =
             base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
@@ -212,16 +229,35 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
       break;
     }
 
+#ifdef SVO_STAMPS
+    { const unsigned long long now = __builtin_readcyclecounter(); st_round += now - st_t0; st_t0 = now; st_nround++; }
+#endif
     // ---------------- traverse until enough lanes have stopped to make a round worthwhile
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
     // (a fixed "N lanes free" trigger was tried instead of the proportional one: 3 % slower at its best setting)
     const int threshold = bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0;
     for (;;) {
+#ifdef SVO_STAMPS
+      if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t, st_load);
+#else
       if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t);
+#endif
       const int active = __builtin_popcountll(__ballot(status == ST_ACTIVE));
+#ifdef SVO_STAMPS
+      st_ntrip++;
+#endif
       if (active <= threshold) break;
     }
+#ifdef SVO_STAMPS
+    { const unsigned long long now = __builtin_readcyclecounter(); st_trav += now - st_t0; st_t0 = now; }
+#endif
   }
+#ifdef SVO_STAMPS
+  if (lane == 0u) {
+    unsigned long long *dbg = (unsigned long long *)(a.heads + 8 * kHeadStride);  // spare words behind the 8 band counters
+    atomicAdd(dbg + 0, st_round); atomicAdd(dbg + 1, st_trav); atomicAdd(dbg + 2, st_nround); atomicAdd(dbg + 3, st_ntrip); atomicAdd(dbg + 4, st_shade); atomicAdd(dbg + 5, st_load);
+  }
+#endif
 }
 
 struct PersistBuffers {
@@ -263,7 +299,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   const size_t npix = (size_t)f.width * (size_t)f.height;
   hipError_t e;
   if (!b.heads) {
-    if ((e = hipMalloc((void **)&b.heads, kHeadSets * 64 * sizeof(uint32_t))) != hipSuccess) return (int)e;
+    if ((e = hipMalloc((void **)&b.heads, kHeadSets * kHeadWords * sizeof(uint32_t))) != hipSuccess) return (int)e;
     int dev = 0, cus = 256, per_cu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -293,8 +329,8 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
   for (int s = 0; s < spp; s++) {
     // a ring of counter sets: frames may be in flight on different streams at the same time
-    a.heads = b.heads + (size_t)(b.launches++ % kHeadSets) * 64;
-    if ((e = hipMemsetAsync(a.heads, 0, 64 * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
+    a.heads = b.heads + (size_t)(b.launches++ % kHeadSets) * kHeadWords;
+    if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
     switch (f.render_mode) {
       case 0: persist_launch_mode<0>(a, blocks, stream); break;

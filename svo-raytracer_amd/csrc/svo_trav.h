@@ -183,7 +183,12 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
 }
 #else
 // one iteration of the loop at svotrace.comp:262-369
-__device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, const uint32_t lane, Trav &t) {
+#ifdef SVO_STAMPS
+#define SVO_STAMP_ARG , unsigned long long &st_load
+#else
+#define SVO_STAMP_ARG
+#endif
+__device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, const uint32_t lane, Trav &t SVO_STAMP_ARG) {
   t.iter++;
   if (t.iter > kMaxIter) return ST_CAPPED;
 #ifdef SVO_DUMMY_VALU
@@ -217,7 +222,14 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
 #else
   t.cptr = t.pbase + child_offset(t.pmask, cs);
 #endif
+#ifdef SVO_STAMPS
+  const unsigned long long l0 = __builtin_readcyclecounter();
+#endif
   t.rec = load_record(pool, t.cptr);
+#ifdef SVO_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st_load += __builtin_readcyclecounter() - l0;
+#endif
   if (rec_value(t.rec) != 0u && t.t_min <= t.t_max) {
     if (kMaxScale - t.scale == t.max_depth) return ST_HIT;
     const float tv_max = vmin(t.t_max, tc_max);

@@ -284,7 +284,11 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
     const int threshold = exhausted ? 0 : (active0 * 5) / 8;  // refill once fewer than 5/8 of them remain
     for (;;) {
+#ifdef SVO_STAMPS
+      { unsigned long long dummy = 0; if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t, dummy); }
+#else
       if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t);
+#endif
       const int active = __builtin_popcountll(__ballot(status == ST_ACTIVE));
       if (active <= threshold) break;
     }
