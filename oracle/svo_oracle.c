@@ -65,6 +65,7 @@ typedef struct svo_oracle_stats {
   uint64_t alg_bytes;  /* 7 per cast (root record) + size of every fetched child record */
   uint64_t max_iter;   /* largest iteration count of a counted ray */
   uint64_t descends, advances, pops; /* iteration mix of counted rays (diagnostic) */
+  uint64_t push_by_scale[24], pop_by_scale[24]; /* stack traffic per level (diagnostic) */
 } svo_oracle_stats;
 
 typedef struct { float x, y, z; } vec3;
@@ -319,6 +320,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
       if (t_min <= tv_max) {
         if (child.cp == 0) { ok = 1; break; }
         if (tc_max < h && scale >= 0 && scale <= MAX_SCALE) { /* guard: index is always 11..22 for pools <= 13 levels deep */
+          if (!is_nan_ray) c->st->push_by_scale[scale]++;
           octstack[scale].node = parent;
           octstack[scale].tmax = t_max;
         }
@@ -354,6 +356,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
       scale = find_msb(differing_bits);
       scale_exp2 = u2f(((uint32_t)scale - (uint32_t)MAX_SCALE + 127u) << 23u);
       if (scale >= 0 && scale <= MAX_SCALE) { /* pin P6: the reference reads out of bounds here; value is dead */
+        if (!is_nan_ray) c->st->pop_by_scale[scale]++;
         parent = octstack[scale].node;
         t_max = octstack[scale].tmax;
       }

@@ -288,6 +288,8 @@ int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_eighths) {
     return fail(c, SVO_E_INVALID, "svo_set_tuning: bad values");
   c->pb.waves_per_cu = waves_per_cu;
   c->pb.thresh_num = round_threshold_eighths ? round_threshold_eighths : 4;
+  c->wf.waves_per_cu = waves_per_cu;
+  c->wf.thresh_num = round_threshold_eighths ? round_threshold_eighths : 6;
   return SVO_OK;
 }
 
@@ -344,7 +346,9 @@ static int launch_frame(svo_ctx *c, bool count) {
     return SVO_OK;
   }
   if (c->pipeline == 2 && !count) {
-    rc = wavefront_launch(c->wf, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, c->stream);
+    const size_t out_npix = std::max((size_t)c->width * (size_t)c->height,
+                                     (size_t)(f.out_y0 + f.tiles_y * 8) * (size_t)c->width);
+    rc = wavefront_launch(c->wf, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, out_npix, c->stream);
     if (rc) return fail(c, SVO_E_HIP, std::string("wavefront pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }

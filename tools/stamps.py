@@ -9,13 +9,14 @@ ctx = hiplib.HipContext(0)
 ctx.pool_upload(pool); ctx.resize(1920, 1080); ctx.set_camera(CAMERAS["K1"]); ctx.set_hit_records(False); ctx.set_pipeline(1)
 L = hiplib.lib()
 L.svo_debug_heads.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-for t in (3, 4, 5, 6, 7):
-    ctx.set_tuning(0, t)
+for wpc in (4, 8, 12, 16, 20):
+    t = 5
+    ctx.set_tuning(wpc, t)
     ctx.set_params(2, 0, 0, 0, 2, 0, 1)
     ms = ctx.time_frames(2, 1)   # 3 launches -> ring slots k, k+1, k+2; read all, take the last launch's set
     buf = np.zeros(32, dtype=np.uint32)
     L.svo_debug_heads(ctx._h, buf.ctypes.data)
     d = buf[0:12].view(np.uint64)
-    nw = 5120
-    print("thresh", t, "ms %.3f" % ms[-1], "rounds/wave %.1f trips/wave %.1f  cyc/round %.0f (shade %.0f, refill+init %.0f)  cyc/trip %.0f (of which load issue->data %.0f)" % (
+    nw = 256 * wpc
+    print("waves/cu", wpc, "thresh", t, "ms %.3f" % ms[-1], "rounds/wave %.1f trips/wave %.1f  cyc/round %.0f (shade %.0f, refill+init %.0f)  cyc/trip %.0f (of which load issue->data %.0f)" % (
         d[2] / nw, d[3] / nw, d[0] / max(d[2], 1), d[4] / max(d[2], 1), (d[0] - d[4]) / max(d[2], 1), d[1] / max(d[3], 1), d[5] / max(d[3], 1)))
