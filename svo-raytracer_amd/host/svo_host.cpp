@@ -33,6 +33,14 @@ int svoh_octree_get_child_pointer(void *o, int p) { return ((Octree *)o)->getChi
 void svoh_octree_set_leaf_mask(void *o, int p, int m) { ((Octree *)o)->setLeafMask(p, (uint16_t)m); }
 int svoh_octree_get_leaf_mask(void *o, int p) { return ((Octree *)o)->getLeafMask(p); }
 
+// OctreeThread.run (OctreeThread.java:20-23): createDummyHead + constructInnerOctree(size, 0, maxLOD, {0,0,0}, 0, voxels)
+void svoh_octree_construct(void *o, int size, int max_lod, const uint8_t *voxels, int chunk) {
+  Octree *oct = (Octree *)o;
+  oct->createDummyHead();
+  const int p[3] = {0, 0, 0};
+  oct->constructInnerOctree(size, 0, max_lod, p, 0, voxels, chunk);
+}
+
 // Octree.useSDFBrush with a Sphere / Box (Main.placeSDF, Main.java:338-353); cb = {start0, end0, start1, end1}
 void svoh_octree_brush_sphere(void *o, int ox, int oy, int oz, int radius, int value, int world_size, int max_lod, int *cb) {
   const int org[3] = {ox, oy, oz};

@@ -156,6 +156,102 @@ class Octree {
            surfaceLeafNodes + nonSurfaceLeafNodes + interiorNodes + subdividableLeafNodes);
   }
 
+
+  // ---- builder from a dense voxel chunk (Octree.java:511-670) -------------------------------------
+  // voxelData is a CHUNK^3 byte grid indexed x | y << shift | z << 2*shift (the reference: 1024^3, shift 10,
+  // Octree.java:110-112).  constructInnerOctree(size, curLOD, maxLOD, pPos, parentPointer, voxelData) appends the
+  // 8 children of the node at parentPointer and recurses, exactly in the reference's order.
+  void constructInnerOctree(int size, int curLOD, int maxLOD, const int pPos[3], int parentPointer,
+                            const uint8_t *voxelData, int chunk = 1024) {
+    const int cSize = size / 2;
+    if (cSize == 0 || curLOD == maxLOD) return;
+    int shift = 0;
+    while ((1 << shift) < chunk) shift++;
+    auto vox = [&](int x, int y, int z) -> uint8_t { return voxelData[(size_t)x | ((size_t)y << shift) | ((size_t)z << (2 * shift))]; };
+    int children[8], cPos[8][3];
+    enum { INTERIOR, SURFACE_LEAF, NON_SURFACE_LEAF, SUBDIVIDABLE_LEAF } types[8];
+    for (int n = 0; n < 8; n++) {
+      cPos[n][0] = pPos[0] + (n & 1) * cSize; cPos[n][1] = pPos[1] + ((n >> 1) & 1) * cSize; cPos[n][2] = pPos[2] + ((n >> 2) & 1) * cSize;
+    }
+    if ((size_t)memOffset + 8 * NODE_SIZE > buffer.size()) buffer.resize(buffer.size() + buffer.size() / 2 + 4096, 0);
+    uint16_t leafMask = 0;
+    for (int n = 0; n < 8; n++) {
+      uint8_t first = vox(cPos[n][0], cPos[n][1], cPos[n][2]), value = first;
+      bool leaf = true;
+      if (curLOD + 1 != maxLOD) {   // :533-555
+        for (int i = cPos[n][2]; i < cPos[n][2] + cSize && leaf; i++)
+          for (int j = cPos[n][1]; j < cPos[n][1] + cSize && leaf; j++)
+            for (int k = cPos[n][0]; k < cPos[n][0] + cSize; k++) {
+              const uint8_t sample = vox(k, j, i);
+              if (sample != 0) value = sample;
+              if (sample != first) {
+                if (first == 0) first = sample;
+                value = first;
+                leaf = false;
+                break;
+              }
+            }
+      }
+      if (leaf && value != 0) {
+        if (cSize == 1) {
+          // genSurfaceNormal (:620-649)
+          bool exposed = false;
+          int nx = 0, ny = 0, nz = 0;
+          for (int i = cPos[n][0] - 1; i <= cPos[n][0] + 1; i++) {
+            if (i < 0 || i >= chunk) continue;
+            for (int j = cPos[n][1] - 1; j <= cPos[n][1] + 1; j++) {
+              if (j < 0 || j >= chunk) continue;
+              for (int k = cPos[n][2] - 1; k <= cPos[n][2] + 1; k++) {
+                if (k < 0 || k >= chunk) continue;
+                if (vox(i, j, k) == 0) { exposed = true; nx += i - cPos[n][0]; ny += j - cPos[n][1]; nz += k - cPos[n][2]; }
+              }
+            }
+          }
+          if (exposed) {
+            children[n] = createSurfaceLeafNode(value, (uint16_t)((nx / 2 + 5) + (ny / 2 + 5) * 10 + (nz / 2 + 5) * 100));
+            types[n] = SURFACE_LEAF;
+          } else {
+            children[n] = createNonSurfaceLeafNode(value);
+            types[n] = NON_SURFACE_LEAF;
+          }
+        } else {
+          // checkBigNodeExposed (:651-670): only coordinates {c-1, c+cSize, c+cSize+1} per axis are examined
+          bool exposed = false;
+          for (int i = cPos[n][2] - 1; i <= cPos[n][2] + cSize + 1; i++) {
+            if (i < 0 || i >= chunk || (i >= cPos[n][2] && i <= cPos[n][2] + cSize - 1)) continue;
+            for (int j = cPos[n][1] - 1; j <= cPos[n][1] + cSize + 1; j++) {
+              if (j < 0 || j >= chunk || (j >= cPos[n][1] && j <= cPos[n][1] + cSize - 1)) continue;
+              for (int k = cPos[n][0] - 1; k <= cPos[n][0] + cSize + 1; k++) {
+                if (k < 0 || k >= chunk || (k >= cPos[n][0] && k <= cPos[n][0] + cSize - 1)) continue;
+                if (vox(k, j, i) == 0) exposed = true;
+              }
+            }
+          }
+          if (exposed) { children[n] = createInteriorNode(value); types[n] = INTERIOR; }
+          else { children[n] = createSubdividableLeafNode(value); types[n] = SUBDIVIDABLE_LEAF; }
+        }
+      } else if (leaf) {
+        if (cSize == 1) { children[n] = createNonSurfaceLeafNode(value); types[n] = NON_SURFACE_LEAF; }
+        else { children[n] = createSubdividableLeafNode(value); types[n] = SUBDIVIDABLE_LEAF; }
+      } else {
+        children[n] = createInteriorNode(value);
+        types[n] = INTERIOR;
+      }
+      switch (types[n]) {   // :589-599
+        case SURFACE_LEAF: leafMask = (uint16_t)(leafMask | (0x0001 << (n << 1))); break;
+        case SUBDIVIDABLE_LEAF: leafMask = (uint16_t)(leafMask | (0x0002 << (n << 1))); break;
+        case NON_SURFACE_LEAF: leafMask = (uint16_t)(leafMask | (0x0003 << (n << 1))); break;
+        case INTERIOR: break;
+      }
+      if ((size_t)memOffset + 8 * NODE_SIZE > buffer.size()) buffer.resize(buffer.size() + buffer.size() / 2 + 4096, 0);
+    }
+    setChildPointer(parentPointer, children[0]);
+    setLeafMask(parentPointer, leafMask);
+    for (int n = 0; n < 8; n++)
+      if (getValue(children[n]) != 0 && types[n] == INTERIOR)
+        constructInnerOctree(cSize, curLOD + 1, maxLOD, cPos[n], children[n], voxelData, chunk);
+  }
+
   // ---- SDF brush edits (Octree.java:672-956): the producer of ranged pool updates ---------------
   struct ChangeBounds {   // :676-688
     int start0, end0, start1, end1;
