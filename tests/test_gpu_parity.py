@@ -238,3 +238,44 @@ def test_config5_8192_1080p_multi_sample_accumulation(ctx, pool8192):
     from svo_raytracer_amd.cameras import CAMERAS
     ctx.set_pipeline(1)
     _check_subsampled(ctx, pool8192, 1920, 1080, CAMERAS["K2"], 2, 0, 40, spp=8)
+
+
+def test_c_abi_error_behaviour():
+    """Status codes instead of exceptions or prints (include/svo_hip.h conventions)."""
+    from svo_raytracer_amd import hiplib
+    c = hiplib.HipContext(0)
+    try:
+        c.resize(64, 48)
+        with pytest.raises(hiplib.SvoError) as e:
+            c.dispatch()                       # no pool yet
+        assert e.value.code == -2              # SVO_E_NOPOOL
+        with pytest.raises(hiplib.SvoError):
+            c.resize(0, 10)
+        with pytest.raises(hiplib.SvoError):
+            c.set_params(2, 0, 0, 0, bounces=0)
+        with pytest.raises(hiplib.SvoError):
+            c.set_pipeline(7)
+        with pytest.raises(hiplib.SvoError):
+            c.set_rows(4, 16)                  # y0 must be a multiple of the 8-pixel tile
+        # an all-zero pool is legal: every ray misses (root value / pointers are 0)
+        c.pool_upload(np.zeros(64, dtype=np.uint8))
+        out = c.render(None, 64, 48, np.asarray([1.5, 1.5, 2.0, -1.6, -0.9, -1, -1.6, 0.9, -1, 1.6, -0.9, -1, 1.6, 0.9, -1],
+                                                dtype=np.float32), 2, 2)
+        assert (out["hits"]["pointer"] == 0).all() and (out["depth"] == 0).all()
+        assert (out["rgba"][:10, :10, :3] == [255, 0, 0]).all()   # first dword 0 -> red debug square
+    finally:
+        c.close()
+
+
+def test_empty_pool_matches_oracle(ctx):
+    from oracle import oracle
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool = np.zeros(64, dtype=np.uint8)
+    for pipeline in PIPELINES:
+        ctx.set_pipeline(pipeline)
+        for mode in (0, 1, 2, 3):
+            got = ctx.render(pool, 72, 40, CAMERAS["K0"], 2, mode)
+            ref = oracle.render(pool, 72, 40, CAMERAS["K0"], 2, mode)
+            assert (got["rgba"] == ref["rgba"]).all(), (pipeline, mode)
+            assert (got["depth"].view(np.uint32) == ref["depth"].view(np.uint32)).all()
+            assert (got["hits"]["iter"] == ref["hits"]["iter"]).all()
