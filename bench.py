@@ -118,7 +118,8 @@ def main():
     # far terrain) and stores them packed in its band of the gather buffer
     s_first, s_step, s_n, s_out0, rows_per_rank = stripe_layout(H_total, world, rank)
     hp = rows_per_rank * world  # padded height so that every rank's band has the same size
-    nbuf = max(2 if use_comm else 1, args.inflight)  # frame k drains / is gathered while frame k+1 is traced
+    nbuf = min(4, max(2 if use_comm else 1, args.inflight))  # frame k drains / is gathered while frame k+1 is traced
+    # (the library keeps a ring of 4+ per-frame work-counter / queue sets, so at most 4 frames may be in flight)
     color = [torch.zeros((hp, W), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
     depth = [torch.zeros((hp, W), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     hits = [torch.zeros((hp, W, 4), dtype=torch.int32, device="cuda") for _ in range(nbuf)] if args.hits else None
