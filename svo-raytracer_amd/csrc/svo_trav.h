@@ -101,87 +101,6 @@ __device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 
   return ST_ACTIVE;
 }
 
-#ifdef SVO_TRAV_PREDICATED
-// one iteration of the loop at svotrace.comp:262-369, written straight-line: the descend and the
-// advance updates are both computed and selected per lane, so that a wave whose lanes disagree executes
-// one instruction stream with two short branches (PUSH store, POP) instead of a nest of exec-mask regions.
-__device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, const uint32_t lane, Trav &t) {
-  t.iter++;
-  if (t.iter > kMaxIter) return ST_CAPPED;
-  t.max_depth = t.t_min > t.cone_t ? 11 : t.max_depth;
-  const float tcx = t.px * t.cx - t.bx;
-  const float tcy = t.py * t.cy - t.by;
-  const float tcz = t.pz * t.cz - t.bz;
-  const float tc_max = vmin3(tcx, tcy, tcz);
-  const uint32_t cs = t.idx ^ t.octant;
-  t.tag = (t.pmask >> (2u * cs)) & 3u;
-  t.cptr = t.pbase + child_offset(t.pmask, cs);
-  t.rec = load_record(pool, t.cptr);
-  const bool nonempty = rec_value(t.rec) != 0u && t.t_min <= t.t_max;
-  const bool at_lod = (kMaxScale - t.scale) == t.max_depth;
-  const float tv_max = vmin(t.t_max, tc_max);
-  const bool in_iv = t.t_min <= tv_max;
-  const uint32_t ccp = t.tag == 0u ? rec_cp(t.rec) : 0u;
-  if (nonempty && (at_lod || (in_iv && ccp == 0u))) return ST_HIT;
-  const bool descend = nonempty && in_iv;
-  // descend candidate
-  const float half = t.sexp * 0.5f;
-  const float tmx = half * t.cx + tcx;
-  const float tmy = half * t.cy + tcy;
-  const float tmz = half * t.cz + tcz;
-  const bool dx = tmx > t.t_min, dy = tmy > t.t_min, dz = tmz > t.t_min;
-  const uint32_t didx = (dx ? 1u : 0u) | (dy ? 2u : 0u) | (dz ? 4u : 0u);
-  // advance candidate
-  const bool ax = tcx <= tc_max, ay = tcy <= tc_max, az = tcz <= tc_max;
-  const uint32_t step = (ax ? 1u : 0u) | (ay ? 2u : 0u) | (az ? 4u : 0u);
-  const uint32_t aidx = t.idx ^ step;
-  if (descend && tc_max < t.h) {  // PUSH
-    const uint32_t lvu = (uint32_t)(t.scale - kStackBase);
-    const uint32_t lv = lvu < (uint32_t)kStackLevels ? lvu : (uint32_t)(kStackLevels - 1);
-    stk.pm[lv * 64 + lane] = make_uint2(t.pbase, __float_as_uint(t.t_max));
-    stk.mk[lv * 64 + lane] = (uint16_t)t.pmask;
-    t.written |= 1u << lv;
-  }
-  const float npx = descend ? (dx ? t.px + half : t.px) : (ax ? t.px - t.sexp : t.px);
-  const float npy = descend ? (dy ? t.py + half : t.py) : (ay ? t.py - t.sexp : t.py);
-  const float npz = descend ? (dz ? t.pz + half : t.pz) : (az ? t.pz - t.sexp : t.pz);
-  t.px = npx; t.py = npy; t.pz = npz;
-  t.h = descend ? tc_max : t.h;
-  t.pbase = descend ? t.cptr + ccp : t.pbase;
-  t.pmask = descend ? rec_mask_be(t.rec) : t.pmask;
-  t.idx = descend ? didx : aidx;
-  t.scale = descend ? t.scale - 1 : t.scale;
-  t.t_max = descend ? tv_max : t.t_max;
-  t.t_min = descend ? t.t_min : tc_max;
-  const float old_sexp = t.sexp;
-  t.sexp = descend ? half : t.sexp;
-  if (!descend && (aidx & step) != 0u) {  // POP
-    uint32_t diff = 0u;
-    if (step & 1u) diff |= __float_as_uint(t.px) ^ __float_as_uint(t.px + old_sexp);
-    if (step & 2u) diff |= __float_as_uint(t.py) ^ __float_as_uint(t.py + old_sexp);
-    if (step & 4u) diff |= __float_as_uint(t.pz) ^ __float_as_uint(t.pz + old_sexp);
-    t.scale = 31 - __builtin_clz(diff | 1u);
-    t.sexp = __uint_as_float(((uint32_t)t.scale - (uint32_t)kMaxScale + 127u) << 23);
-    const uint32_t lvu = (uint32_t)(t.scale - kStackBase);
-    const uint32_t lv = lvu < (uint32_t)kStackLevels ? lvu : 0u;
-    const bool have = lvu < (uint32_t)kStackLevels && ((t.written >> lv) & 1u);
-    const uint2 e = stk.pm[lv * 64 + lane];
-    const uint32_t m = stk.mk[lv * 64 + lane];
-    t.pbase = have ? e.x : 0u;
-    t.t_max = have ? __uint_as_float(e.y) : 0.0f;
-    t.pmask = have ? m : 0u;
-    const uint32_t sh = (uint32_t)t.scale & 31u;
-    const uint32_t sx = __float_as_uint(t.px) >> sh, sy = __float_as_uint(t.py) >> sh, sz = __float_as_uint(t.pz) >> sh;
-    t.px = __uint_as_float(sx << sh);
-    t.py = __uint_as_float(sy << sh);
-    t.pz = __uint_as_float(sz << sh);
-    t.idx = (sx & 1u) | ((sy & 1u) << 1) | ((sz & 1u) << 2);
-    t.h = 0.0f;
-    if (t.scale >= kMaxScale) return ST_MISS;
-  }
-  return ST_ACTIVE;
-}
-#else
 // one iteration of the loop at svotrace.comp:262-369
 #ifdef SVO_STAMPS
 #define SVO_STAMP_ARG , unsigned long long &st_load
@@ -191,14 +110,6 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
 __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, const uint32_t lane, Trav &t SVO_STAMP_ARG) {
   t.iter++;
   if (t.iter > kMaxIter) return ST_CAPPED;
-#ifdef SVO_DUMMY_VALU
-  {  // experiment: extra dependent-free VALU work to test whether the loop is issue-bound
-    float x = t.h;
-#pragma unroll
-    for (int i = 0; i < SVO_DUMMY_VALU; i++) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
-    asm volatile("" ::"v"(x));
-  }
-#endif
   if (t.t_min > t.cone_t) t.max_depth = 11;
   const float tcx = t.px * t.cx - t.bx;
   const float tcy = t.py * t.cy - t.by;
@@ -206,22 +117,8 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
   const float tc_max = vmin3(tcx, tcy, tcz);
   const uint32_t cs = t.idx ^ t.octant;
   t.tag = (t.pmask >> (2u * cs)) & 3u;
-#ifdef SVO_DIET2
-  {
-    // 7c - 2*(2*popc(lo) + popc(lo & hi)) with v_bcnt's accumulate operand
-    const uint32_t below = ~(~0u << (2u * cs));
-    const uint32_t lo = t.pmask & 0x5555u & below;
-    const uint32_t both = lo & (t.pmask >> 1);
-    uint32_t acc, base7;
-    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc) : "v"(lo));
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"(lo), "v"(acc));
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"(both), "v"(acc));
-    asm("v_mad_u32_u24 %0, %1, 7, %2" : "=v"(base7) : "v"(cs), "v"(t.pbase));
-    asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(t.cptr) : "v"(acc), "v"(base7));
-  }
-#else
   t.cptr = t.pbase + child_offset(t.pmask, cs);
-#endif
+
 #ifdef SVO_STAMPS
   const unsigned long long l0 = __builtin_readcyclecounter();
 #endif
@@ -295,8 +192,6 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
   }
   return ST_ACTIVE;
 }
-
-#endif  // SVO_TRAV_PREDICATED
 
 // result part of the cast (svotrace.comp:371-431)
 __device__ __forceinline__ Cast trav_result(const Trav &t, int status) {
