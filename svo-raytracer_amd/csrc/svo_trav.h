@@ -57,7 +57,7 @@ struct Trav {
   float cx, cy, cz, bx, by, bz;
   float px, py, pz;
   float t_min, t_max, h, sexp;
-  int scale, max_depth;
+  int scale, lod_scale;   // lod_scale = kMaxScale - maxDepth: a non-empty child met at this scale is a hit
   float cone_t;   // t_min beyond which a cone (secondary) ray drops to LOD 11; +inf for other rays
   uint32_t idx, octant, pbase, pmask, written, iter;
   uint32_t cptr, tag;
@@ -70,7 +70,7 @@ enum : int { ST_SKIP = -1, ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, 
 // `root` = the root record (svotrace.comp:222), fetched once per wave by the caller
 __device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 d, const bool cone) {
   t.cone_t = cone ? 0.05f : __builtin_inff();
-  t.iter = 0; t.cptr = 0; t.tag = 0; t.rec = 0; t.written = 0; t.max_depth = kMaxDepth;
+  t.iter = 0; t.cptr = 0; t.tag = 0; t.rec = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
   if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
     t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0; t.idx = 0;
@@ -110,7 +110,7 @@ __device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 
 __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, const uint32_t lane, Trav &t SVO_STAMP_ARG) {
   t.iter++;
   if (t.iter > kMaxIter) return ST_CAPPED;
-  if (t.t_min > t.cone_t) t.max_depth = 11;
+  if (t.t_min > t.cone_t) t.lod_scale = kMaxScale - 11;
   const float tcx = t.px * t.cx - t.bx;
   const float tcy = t.py * t.cy - t.by;
   const float tcz = t.pz * t.cz - t.bz;
@@ -128,7 +128,7 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
   st_load += __builtin_readcyclecounter() - l0;
 #endif
   if (rec_value(t.rec) != 0u && t.t_min <= t.t_max) {
-    if (kMaxScale - t.scale == t.max_depth) return ST_HIT;
+    if (t.scale == t.lod_scale) return ST_HIT;
     const float tv_max = vmin(t.t_max, tc_max);
     if (t.t_min <= tv_max) {
       const uint32_t ccp = t.tag == 0u ? rec_cp(t.rec) : 0u;
@@ -158,17 +158,19 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
     }
   }
   uint32_t step = 0u;
+  const float opx = t.px, opy = t.py, opz = t.pz;
   if (tcx <= tc_max) { step ^= 1u; t.px -= t.sexp; }
   if (tcy <= tc_max) { step ^= 2u; t.py -= t.sexp; }
   if (tcz <= tc_max) { step ^= 4u; t.pz -= t.sexp; }
   t.t_min = tc_max;
   t.idx ^= step;
   if ((t.idx & step) != 0u) {  // POP
-    uint32_t diff = 0u;
-    if (step & 1u) diff |= __float_as_uint(t.px) ^ __float_as_uint(t.px + t.sexp);
-    if (step & 2u) diff |= __float_as_uint(t.py) ^ __float_as_uint(t.py + t.sexp);
-    if (step & 4u) diff |= __float_as_uint(t.pz) ^ __float_as_uint(t.pz + t.sexp);
-    // diff != 0 always (pos and pos + cell size differ); v_ffbh of 0 would give scale 32 -> treated as exit
+    // the reference XORs pos with pos + cell size on every stepped axis; pos + cell size is exactly the
+    // position before the step (all values are multiples of the cell size), and an axis that did not step
+    // contributes zero, so the differing bits are simply old ^ new on all three axes
+    const uint32_t diff = (__float_as_uint(t.px) ^ __float_as_uint(opx)) | (__float_as_uint(t.py) ^ __float_as_uint(opy)) |
+                          (__float_as_uint(t.pz) ^ __float_as_uint(opz));
+    // diff != 0 always (a stepped axis changed); |1 only keeps clz defined
     t.scale = 31 - __builtin_clz(diff | 1u);
     t.sexp = __uint_as_float(((uint32_t)t.scale - (uint32_t)kMaxScale + 127u) << 23);
     // restore {child-block base, t_max, tag mask} of that level; a level this ray never pushed reads as the
