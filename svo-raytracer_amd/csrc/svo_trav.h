@@ -51,6 +51,13 @@ __device__ __forceinline__ uint64_t load_record(const BufPool &pool, uint32_t p)
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(pool.rsrc, (int)p, 0, 0);
   return ((uint64_t)v.y << 32) | (uint64_t)v.x;
 }
+__device__ __forceinline__ u32x2 load_record2(const BufPool &pool, uint32_t p) {
+  return __builtin_amdgcn_raw_buffer_load_b64(pool.rsrc, (int)p, 0, 0);
+}
+// field decoders on the two dwords of a record: one v_perm_b32 each
+// (selector bytes 0..3 address the second operand, 4..7 the first, 0x0c = constant zero)
+__device__ __forceinline__ uint32_t rec2_cp(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x01020304u); }
+__device__ __forceinline__ uint32_t rec2_mask_be(uint32_t hi) { return __builtin_amdgcn_perm(hi, hi, 0x0c0c0102u); }
 
 // Traversal state of one ray, held in registers across refill rounds.
 struct Trav {
@@ -61,7 +68,7 @@ struct Trav {
   float cone_t;   // t_min beyond which a cone (secondary) ray drops to LOD 11; +inf for other rays
   uint32_t idx, octant, pbase, pmask, written, iter;
   uint32_t cptr, tag;
-  uint64_t rec;
+  uint32_t rlo, rhi;   // the record at cptr (bytes 0..3, 4..7)
 };
 
 enum : int { ST_SKIP = -1, ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, ST_CAPPED = 4 };
@@ -70,7 +77,7 @@ enum : int { ST_SKIP = -1, ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, 
 // `root` = the root record (svotrace.comp:222), fetched once per wave by the caller
 __device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 d, const bool cone) {
   t.cone_t = cone ? 0.05f : __builtin_inff();
-  t.iter = 0; t.cptr = 0; t.tag = 0; t.rec = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
+  t.iter = 0; t.cptr = 0; t.tag = 0; t.rlo = 0; t.rhi = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
   if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
     t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0; t.idx = 0;
@@ -117,21 +124,27 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
   const float tc_max = vmin3(tcx, tcy, tcz);
   const uint32_t cs = t.idx ^ t.octant;
   t.tag = (t.pmask >> (2u * cs)) & 3u;
-  t.cptr = t.pbase + child_offset(t.pmask, cs);
+  {  // child_offset(): 7 * cs - 4 * popcount(lo) - 2 * popcount(both), kept in 32-bit full-rate instructions
+    const uint32_t below = (1u << (2u * cs)) - 1u;
+    const uint32_t lo = t.pmask & 0x5555u & below;
+    const uint32_t both = lo & (t.pmask >> 1);
+    const uint32_t w = (uint32_t)__builtin_popcount(both) + 2u * (uint32_t)__builtin_popcount(lo);
+    t.cptr = (__umul24(cs, 7u) + t.pbase) - 2u * w;
+  }
 
 #ifdef SVO_STAMPS
   const unsigned long long l0 = __builtin_readcyclecounter();
 #endif
-  t.rec = load_record(pool, t.cptr);
+  { const u32x2 rr = load_record2(pool, t.cptr); t.rlo = rr.x; t.rhi = rr.y; }
 #ifdef SVO_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   st_load += __builtin_readcyclecounter() - l0;
 #endif
-  if (rec_value(t.rec) != 0u && t.t_min <= t.t_max) {
+  if ((t.rlo & 0xffu) != 0u && t.t_min <= t.t_max) {
     if (t.scale == t.lod_scale) return ST_HIT;
     const float tv_max = vmin(t.t_max, tc_max);
     if (t.t_min <= tv_max) {
-      const uint32_t ccp = t.tag == 0u ? rec_cp(t.rec) : 0u;
+      const uint32_t ccp = t.tag == 0u ? rec2_cp(t.rlo, t.rhi) : 0u;
       if (ccp == 0u) return ST_HIT;
       const float half = t.sexp * 0.5f;
       const float tmx = half * t.cx + tcx;
@@ -139,14 +152,15 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
       const float tmz = half * t.cz + tcz;
       if (tc_max < t.h) {  // PUSH (scale is 11..22 for pools up to 13 levels; clamp keeps LDS accesses in range)
         const uint32_t lvu = (uint32_t)(t.scale - kStackBase);
-        const uint32_t lv = lvu < (uint32_t)kStackLevels ? lvu : (uint32_t)(kStackLevels - 1);
-        stk.pm[lv * 64 + lane] = make_uint2(t.pbase, __float_as_uint(t.t_max));
-        stk.mk[lv * 64 + lane] = (uint16_t)t.pmask;
+        const uint32_t lv = lvu < (uint32_t)(kStackLevels - 1) ? lvu : (uint32_t)(kStackLevels - 1);
+        const uint32_t slot = (lv << 6) | lane;
+        *(uint2 *)((char *)stk.pm + (slot << 3)) = make_uint2(t.pbase, __float_as_uint(t.t_max));
+        *(uint16_t *)((char *)stk.mk + (slot << 1)) = (uint16_t)t.pmask;
         t.written |= 1u << lv;
       }
       t.h = tc_max;
       t.pbase = t.cptr + ccp;
-      t.pmask = rec_mask_be(t.rec);
+      t.pmask = rec2_mask_be(t.rhi);
       t.idx = 0u;
       --t.scale;
       t.sexp = half;
@@ -175,20 +189,24 @@ __device__ __forceinline__ int trav_step(const BufPool &pool, WaveStack &stk, co
     t.sexp = __uint_as_float(((uint32_t)t.scale - (uint32_t)kMaxScale + 127u) << 23);
     // restore {child-block base, t_max, tag mask} of that level; a level this ray never pushed reads as the
     // reference's zero-initialised stack entry
+    // (scale is 0..30 here; `written` only ever has bits 0..11 set, so the shift by (scale - 11) mod 32 is
+    // also the range check)
     const uint32_t lvu = (uint32_t)(t.scale - kStackBase);
-    const uint32_t lv = lvu < (uint32_t)kStackLevels ? lvu : 0u;
-    const bool have = lvu < (uint32_t)kStackLevels && ((t.written >> lv) & 1u);
-    const uint2 e = stk.pm[lv * 64 + lane];
-    const uint32_t m = stk.mk[lv * 64 + lane];
+    const uint32_t lv = lvu < (uint32_t)(kStackLevels - 1) ? lvu : (uint32_t)(kStackLevels - 1);
+    const bool have = ((t.written >> (lvu & 31u)) & 1u) != 0u;
+    const uint32_t slot = (lv << 6) | lane;
+    const uint2 e = *(const uint2 *)((const char *)stk.pm + (slot << 3));
+    const uint32_t m = *(const uint16_t *)((const char *)stk.mk + (slot << 1));
     t.pbase = have ? e.x : 0u;
     t.t_max = have ? __uint_as_float(e.y) : 0.0f;
     t.pmask = have ? m : 0u;
     const uint32_t sh = (uint32_t)t.scale & 31u;
-    const uint32_t sx = __float_as_uint(t.px) >> sh, sy = __float_as_uint(t.py) >> sh, sz = __float_as_uint(t.pz) >> sh;
-    t.px = __uint_as_float(sx << sh);
-    t.py = __uint_as_float(sy << sh);
-    t.pz = __uint_as_float(sz << sh);
-    t.idx = (sx & 1u) | ((sy & 1u) << 1) | ((sz & 1u) << 2);
+    const uint32_t keep = ~0u << sh;
+    const uint32_t bx = __float_as_uint(t.px) & keep, by = __float_as_uint(t.py) & keep, bz = __float_as_uint(t.pz) & keep;
+    t.px = __uint_as_float(bx);
+    t.py = __uint_as_float(by);
+    t.pz = __uint_as_float(bz);
+    t.idx = __builtin_amdgcn_ubfe(bx, sh, 1u) | (__builtin_amdgcn_ubfe(by, sh, 1u) << 1) | (__builtin_amdgcn_ubfe(bz, sh, 1u) << 2);
     t.h = 0.0f;
     if (t.scale >= kMaxScale) return ST_MISS;
   }
@@ -207,8 +225,8 @@ __device__ __forceinline__ Cast trav_result(const Trav &t, int status) {
   res.scale_exp2 = t.sexp;
   if (!res.hit) return res;
   uint32_t raw = 0u;
-  if (t.tag == 1u) raw = rec_normal_le(t.rec);
-  else if (t.tag != 3u) raw = rec_mask_be(t.rec);
+  if (t.tag == 1u) raw = (t.rlo >> 8) & 0xffffu;   // packed normal, u16 little-endian in bytes 1..2
+  else if (t.tag != 3u) raw = rec2_mask_be(t.rhi);
   V3 n = mk(0.f, 0.f, 0.f);
   if (raw != 0u) {
     const int r = (int)raw;
@@ -218,7 +236,7 @@ __device__ __forceinline__ Cast trav_result(const Trav &t, int status) {
     n = normalize3(mk(nx, ny, nz));
   }
   res.pointer = t.cptr;
-  res.value = rec_value(t.rec);
+  res.value = t.rlo & 0xffu;
   res.raw = raw;
   res.level = (uint32_t)(kMaxScale - t.scale);
   res.normal = n;

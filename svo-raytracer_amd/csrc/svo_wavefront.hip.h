@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64, SVO_TRACE_WAVES_PER_SIMD) void wf_trace_kernel(
     // ---- finished lanes: store the raw result
     if (status >= ST_HIT) {
       uint4 r0, r1;
-      r0.x = t.cptr; r0.y = (uint32_t)t.rec; r0.z = (uint32_t)(t.rec >> 32); r0.w = __float_as_uint(t.t_min);
+      r0.x = t.cptr; r0.y = t.rlo; r0.z = t.rhi; r0.w = __float_as_uint(t.t_min);
       r1.x = __float_as_uint(t.px); r1.y = __float_as_uint(t.py); r1.z = __float_as_uint(t.pz);
       r1.w = (t.iter & 0x7ffu) | (((uint32_t)t.scale & 0x3fu) << 11) | ((t.octant & 7u) << 17) | ((t.tag & 3u) << 20) |
              ((uint32_t)status << 22);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const WfArgs a) {
     const uint4 r0 = a.results[2 * (size_t)slot], r1 = a.results[2 * (size_t)slot + 1];
     // rebuild what trav_result needs
     Trav t;
-    t.cptr = r0.x; t.rec = ((uint64_t)r0.z << 32) | (uint64_t)r0.y; t.t_min = __uint_as_float(r0.w);
+    t.cptr = r0.x; t.rlo = r0.y; t.rhi = r0.z; t.t_min = __uint_as_float(r0.w);
     t.px = __uint_as_float(r1.x); t.py = __uint_as_float(r1.y); t.pz = __uint_as_float(r1.z);
     t.iter = r1.w & 0x7ffu;
     t.scale = (int)((r1.w >> 11) & 0x3fu);
