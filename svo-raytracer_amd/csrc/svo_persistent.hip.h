@@ -18,6 +18,7 @@
 #pragma once
 #include "svo_fused.hip.h"
 #include "svo_trav.h"
+#include "svo_travloop.h"
 
 #include <cstdlib>
 
@@ -66,6 +67,21 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
   if (a.sample == 0) a.depth[pix] = depth;
 }
 
+// SVO_ASM_LOOP=1 (default): the trips run in trav_loop() (svo_travloop.h, gfx950 assembly);
+// SVO_ASM_LOOP=0: hipcc's translation of trav_step() -- same results, kept for A/B runs and as the readable form.
+#ifndef SVO_ASM_LOOP
+#define SVO_ASM_LOOP 1
+#endif
+#if SVO_ASM_LOOP && !defined(SVO_STAMPS)
+#define SVO_TRAV_T TravRegs
+#define SVO_TRAV_INIT trav_init_regs
+#define SVO_TRAV_RESULT trav_result_regs
+#else
+#define SVO_TRAV_T Trav
+#define SVO_TRAV_INIT trav_init
+#define SVO_TRAV_RESULT trav_result
+#endif
+
 #ifndef SVO_PERSIST_WAVES_PER_SIMD
 #define SVO_PERSIST_WAVES_PER_SIMD 5
 #endif
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
   const V3 cam_o = mk(f.cam[0], f.cam[1], f.cam[2]);
   const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
 
-  Trav t;
+  SVO_TRAV_T t;
   int status = ST_IDLE;
   uint32_t pix = 0, seg = 0;
   int px = 0, py = 0;
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
     if (status >= ST_HIT) {
-      const Cast c = trav_result(t, status);
+      const Cast c = SVO_TRAV_RESULT(t, status);
       status = ST_IDLE;
       if (seg == 0u && f.write_hits && a.sample == 0) {
         uint4 h;
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             } else {
               d = nd;
               seg++;
-              status = trav_init(root, t, vpos, nd, true);
+              status = SVO_TRAV_INIT(root, t, vpos, nd, true);
             }
           } else {
             const V3 sun = normalize3(mk(1.0f, 1.0f, 1.0f));
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             mask = mc;
             depth = c.t;
             seg = 1u;
-            status = trav_init(root, t, c.voxel_pos, sun2, false);
+            status = SVO_TRAV_INIT(root, t, c.voxel_pos, sun2, false);
           } else {
             persist_emit(a, pix, px, py, sky_colour(d), 0.0f);
           }
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             value = 0u;
             depth = 0.0f;
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
-            status = trav_init(root, t, cam_o, d, false);
+            status = SVO_TRAV_INIT(root, t, cam_o, d, false);
           }
         }
         if (base + n >= band_total) {  // this band is used up: move on (work stealing)
@@ -235,7 +251,13 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     // ---------------- traverse until enough lanes have stopped to make a round worthwhile
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
     // (a fixed "N lanes free" trigger was tried instead of the proportional one: 3 % slower at its best setting)
-    const int threshold = bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0;
+    const int threshold = __builtin_amdgcn_readfirstlane(bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0);
+#if SVO_ASM_LOOP && !defined(SVO_STAMPS)
+    {
+      const unsigned long long act = __ballot(status == ST_ACTIVE);
+      if (act != 0ull) trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold));
+    }
+#else
     for (;;) {
 #ifdef SVO_STAMPS
       if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t, st_load);
@@ -248,6 +270,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #endif
       if (active <= threshold) break;
     }
+#endif
 #ifdef SVO_STAMPS
     { const unsigned long long now = __builtin_readcyclecounter(); st_trav += now - st_t0; st_t0 = now; }
 #endif

@@ -1,0 +1,308 @@
+// svo_travloop.h -- the traversal trips of a persistent wave, written in gfx950 assembly.
+//
+// trav_loop() runs trav_step() (svo_trav.h, the readable statement of the same arithmetic) on
+// the wave's active lanes until no more than `threshold` of them are still traversing.  The
+// instruction stream is the kernel's critical resource: a wave64 VALU instruction holds its
+// SIMD for 4 cycles and every trip executes the descend, advance and pop sections one after the
+// other for whichever lanes need them, so the frame time is proportional to the number of
+// vector instructions in this loop.  hipcc's version of the loop is 123 vector instructions per
+// trip (phi copies on the back edge, status bookkeeping in a VGPR, hazard nops); this one is 98:
+//   * lane sets (active / hit / descend / advance / pop) live in SGPR pairs and are combined
+//     on the scalar unit; the status VGPR is only written when a lane stops;
+//   * the three per-axis comparisons feed carry chains (v_addc_co_u32) that build the 3-bit
+//     child index, and selected increments (0 or the cell size) that update the position in
+//     place -- no old/new copies of the position;
+//   * the pushed {child-block base, t_max} pair goes to LDS with one ds_write2_b32 from the two
+//     registers where they live.
+// Arithmetic, operand order and rounding are those of trav_step(); the parity tests run both.
+//
+// Hazards observed (gfx950): a VALU write of an SGPR pair / VCC needs two other instructions
+// before a VALU reads it as a mask (v_cndmask, v_addc); SALU reads are interlocked.  Loads are
+// counted here (s_waitcnt vmcnt(0) / lgkmcnt(0) inside the block).
+//
+// Registers are pinned (the asm needs both halves and the whole of the y/z pairs):
+//   v56 cx   v57 bx   v[58:59] cy,cz   v[60:61] by,bz   v62 octant   v63 cone_t
+//   v64 &pm[lane]   v65 &mk[lane]
+//   v67 px   v[68:69] py,pz   v70 t_min   v71 t_max   v72 cell size   v73 h   v74 scale
+//   v75 idx  v76 pbase   v77 pmask   v78 written   v79 iter   v80 lod scale   v81 status
+//   v82 cptr v83 tag   v[88:89] record of the last visited child
+//   temporaries v84 tcx  v85 tc_max  v[86:87] tcy,tcz  v90 v91 v[92:93] v94 v95
+#pragma once
+#include "svo_trav.h"
+
+namespace svo {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// per-ray constants and state in the register layout of trav_loop()
+struct TravRegs {
+  float cx, bx;
+  f32x2 cyz, byz;
+  uint32_t octant;
+  float cone_t;
+  float px;
+  f32x2 pyz;
+  float t_min, t_max, sexp, h;
+  int scale;
+  uint32_t idx, pbase, pmask, written, iter;
+  int lod_scale;
+  uint32_t cptr, tag, rlo, rhi;
+};
+
+// set-up part of the cast (svotrace.comp:221-260)
+// `root` = the root record (svotrace.comp:222), fetched once per wave by the caller
+__device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, V3 o, V3 d, const bool cone) {
+  t.cone_t = cone ? 0.05f : __builtin_inff();
+  t.iter = 0; t.cptr = 0; t.tag = 0; t.rlo = 0; t.rhi = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
+  t.scale = kMaxScale - 1; t.sexp = 0.5f;
+  if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
+    t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0; t.idx = 0;
+    t.cx = t.cyz.x = t.cyz.y = t.bx = t.byz.x = t.byz.y = 0.0f; t.px = t.pyz.x = t.pyz.y = 1.0f; t.pbase = 0; t.pmask = 0;
+    return ST_CAPPED;
+  }
+  if (__builtin_fabsf(d.x) < kEpsilon) d.x = kEpsilon * sign_g(d.x);
+  if (__builtin_fabsf(d.y) < kEpsilon) d.y = kEpsilon * sign_g(d.y);
+  if (__builtin_fabsf(d.z) < kEpsilon) d.z = kEpsilon * sign_g(d.z);
+  t.cx = 1.0f / -__builtin_fabsf(d.x);
+  t.cyz.x = 1.0f / -__builtin_fabsf(d.y);
+  t.cyz.y = 1.0f / -__builtin_fabsf(d.z);
+  t.bx = t.cx * o.x; t.byz.x = t.cyz.x * o.y; t.byz.y = t.cyz.y * o.z;
+  t.octant = 0;
+  if (d.x > 0.0f) { t.octant ^= 1u; t.bx = 3.0f * t.cx - t.bx; }
+  if (d.y > 0.0f) { t.octant ^= 2u; t.byz.x = 3.0f * t.cyz.x - t.byz.x; }
+  if (d.z > 0.0f) { t.octant ^= 4u; t.byz.y = 3.0f * t.cyz.y - t.byz.y; }
+  t.t_min = vmax3(2.0f * t.cx - t.bx, 2.0f * t.cyz.x - t.byz.x, 2.0f * t.cyz.y - t.byz.y);
+  t.t_max = vmin3(t.cx - t.bx, t.cyz.x - t.byz.x, t.cyz.y - t.byz.y);
+  t.t_min = vmax(t.t_min, 0.0f);
+  t.h = t.t_max;
+  t.idx = 0; t.px = 1.0f; t.pyz.x = 1.0f; t.pyz.y = 1.0f;
+  if (1.5f * t.cx - t.bx > t.t_min) { t.idx ^= 1u; t.px = 1.5f; }
+  if (1.5f * t.cyz.x - t.byz.x > t.t_min) { t.idx ^= 2u; t.pyz.x = 1.5f; }
+  if (1.5f * t.cyz.y - t.byz.y > t.t_min) { t.idx ^= 4u; t.pyz.y = 1.5f; }
+  t.pbase = rec_cp(root);
+  t.pmask = rec_mask_be(root);
+  return ST_ACTIVE;
+}
+
+
+// result part of the cast (svotrace.comp:371-431)
+__device__ __forceinline__ Cast trav_result_regs(const TravRegs &t, int status) {
+  Cast res;
+  res.hit = status == ST_HIT;
+  res.capped = status == ST_CAPPED;
+  res.pointer = 0; res.value = 0; res.raw = 0; res.level = 0;
+  res.normal = mk(0.f, 0.f, 0.f); res.voxel_pos = mk(0.f, 0.f, 0.f);
+  res.iter = t.iter;
+  res.t = t.t_min;
+  res.scale_exp2 = t.sexp;
+  if (!res.hit) return res;
+  uint32_t raw = 0u;
+  if (t.tag == 1u) raw = (t.rlo >> 8) & 0xffffu;   // packed normal, u16 little-endian in bytes 1..2
+  else if (t.tag != 3u) raw = rec2_mask_be(t.rhi);
+  V3 n = mk(0.f, 0.f, 0.f);
+  if (raw != 0u) {
+    const int r = (int)raw;
+    const float nx = (float)((r % 10) - 5);
+    const float ny = (float)((((r % 100) - (r % 10)) / 10) - 5);
+    const float nz = (float)(((r - (r % 100)) / 100) - 5);
+    n = normalize3(mk(nx, ny, nz));
+  }
+  res.pointer = t.cptr;
+  res.value = t.rlo & 0xffu;
+  res.raw = raw;
+  res.level = (uint32_t)(kMaxScale - t.scale);
+  res.normal = n;
+  float vx = t.px, vy = t.pyz.x, vz = t.pyz.y;
+  if (t.octant & 1u) vx = 3.0f - vx - t.sexp;
+  if (t.octant & 2u) vy = 3.0f - vy - t.sexp;
+  if (t.octant & 4u) vz = 3.0f - vz - t.sexp;
+  vx += ((n.x * t.sexp) * 2.0f) * 1.74f;
+  vy += ((n.y * t.sexp) * 2.0f) * 1.74f;
+  vz += ((n.z * t.sexp) * 2.0f) * 1.74f;
+  res.voxel_pos = mk(vx, vy, vz);
+  return res;
+}
+
+
+// LDS byte offset of a __shared__ object
+template <typename T>
+__device__ __forceinline__ uint32_t lds_offset(T *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) T *)p;
+}
+
+// Run trips until at most `threshold` lanes of `act` (the lanes with status == ST_ACTIVE) are still traversing.
+// Lanes that stop get their status (ST_HIT / ST_MISS / ST_CAPPED); r.rlo/r.rhi are then the hit record.
+__device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, const uint32_t lane, TravRegs &r,
+                                          int &status, unsigned long long act, const int threshold) {
+  const uint32_t lds8 = lds_offset(&stk.pm[lane]);
+  const uint32_t lds2 = lds_offset(&stk.mk[lane]);
+  unsigned long long sv, sa, sb, sc, sd, se, sf;
+  int cnt;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n"
+      "Ltrip%=:\n\t"
+      "s_mov_b64 exec, %[act]\n\t"
+      // ---- child slot, iteration cap (svotrace.comp:263-266)
+      "v_xor_b32 v90, v75, v62\n\t"                       // cs = idx ^ octant
+      "v_add_u32 v79, 1, v79\n\t"                         // iter++
+      "v_lshlrev_b32 v91, 1, v90\n\t"                     // 2 cs
+      "v_cmp_lt_u32 vcc, 0x5dc, v79\n\t"                  // iter > 1500
+      "v_lshrrev_b32 v94, 1, v77\n\t"
+      "v_bfe_u32 v83, v77, v91, 2\n\t"                    // tag of the child
+      "v_lshlrev_b32_e64 v91, v91, -1\n\t"                // ~(children below cs)
+      "v_cndmask_b32_e64 v81, v81, 4, vcc\n\t"            // capped lanes: status = ST_CAPPED ...
+      "s_andn2_b64 %[act], %[act], vcc\n\t"               // ... and out of the loop
+      "s_andn2_b64 exec, exec, vcc\n\t"
+      // byte offset of child cs in its sibling block: 7 cs - 4 popcount(lo) - 2 popcount(both)
+      "v_bitop3_b32 v91, v77, %[k5555], v91 bitop3:0x40\n\t"   // lo = pmask & 0x5555 & below
+      "v_and_b32 v94, v91, v94\n\t"                       // both = lo & (pmask >> 1)
+      "v_bcnt_u32_b32 v94, v94, 0\n\t"
+      "v_bcnt_u32_b32 v94, v91, v94\n\t"
+      "v_bcnt_u32_b32 v94, v91, v94\n\t"                  // popcount(both) + 2 popcount(lo)
+      "v_mad_u32_u24 v82, v90, 7, v76\n\t"
+      "v_mad_i32_i24 v82, v94, -2, v82\n\t"               // cptr
+      "buffer_load_dwordx2 v[88:89], v82, %[rs], 0 offen\n\t"
+      // ---- exit distances of the current cell (svotrace.comp:268-269)
+      "v_mul_f32 v84, v67, v56\n\t"
+      "v_pk_mul_f32 v[86:87], v[68:69], v[58:59]\n\t"
+      "v_cmp_gt_f32 vcc, v70, v63\n\t"                    // t_min > cone_t: cone rays drop to LOD 11 (sticky)
+      "v_sub_f32 v84, v84, v57\n\t"
+      "v_pk_add_f32 v[86:87], v[86:87], v[60:61] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_cmp_le_f32_e64 %[sa], v70, v71\n\t"              // t_min <= t_max
+      "v_cndmask_b32_e64 v80, v80, 12, vcc\n\t"
+      "v_min3_f32 v85, v84, v86, v87\n\t"                 // tc_max
+      "v_min_f32 v95, v71, v85\n\t"                       // tv_max
+      "v_cmp_eq_u32_e64 %[sb], v74, v80\n\t"              // at the LOD scale
+      "v_cmp_le_f32_e64 %[sc], v70, v95\n\t"              // t_min <= tv_max
+      "v_cmp_eq_u32_e64 %[sd], 0, v83\n\t"                // interior tag
+      "s_waitcnt vmcnt(0)\n\t"
+      "v_cmp_ne_u32_sdwa %[se], v88, %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // value != 0
+      "v_perm_b32 v91, v89, v88, %[selcp]\n\t"            // child pointer (big-endian bytes 1..4)
+      "v_cmp_ne_u32_e64 vcc, 0, v91\n\t"
+      // lane sets
+      "s_and_b64 %[sa], %[sa], %[se]\n\t"                 // N = non-empty and in range
+      "s_and_b64 %[sd], %[sd], vcc\n\t"                   // has a child block
+      "s_andn2_b64 %[se], %[sc], %[sd]\n\t"
+      "s_or_b64 %[se], %[se], %[sb]\n\t"
+      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // HIT = N & (at LOD | (inside & no child block))
+      "s_and_b64 %[sd], %[sd], %[sc]\n\t"
+      "s_andn2_b64 %[sd], %[sd], %[sb]\n\t"
+      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = N & !at LOD & inside & child block
+      "s_or_b64 %[sa], %[se], %[sd]\n\t"
+      "s_andn2_b64 %[sa], exec, %[sa]\n\t"                // ADVANCE = the rest
+      "s_cmp_eq_u64 %[se], 0\n\t"
+      "s_cbranch_scc1 Lnohit%=\n\t"
+      "s_mov_b64 exec, %[se]\n\t"
+      "v_mov_b32 v81, 2\n\t"                              // ST_HIT
+      "s_andn2_b64 %[act], %[act], %[se]\n"
+      "Lnohit%=:\n\t"
+      // ---- DESCEND (svotrace.comp:291-327)
+      "s_mov_b64 exec, %[sd]\n\t"
+      "s_cbranch_execz LnoD%=\n\t"
+      "v_cmp_lt_f32 vcc, v85, v73\n\t"                    // tc_max < h: PUSH
+      "v_mul_f32 v72, 0.5, v72\n\t"                       // half
+      "v_add_u32 v90, -11, v74\n\t"
+      "v_min_u32 v90, 11, v90\n\t"                        // stack level
+      "s_and_saveexec_b64 %[sb], vcc\n\t"
+      "v_lshl_add_u32 v94, v90, 9, v64\n\t"
+      "v_lshl_add_u32 v92, v90, 7, v65\n\t"
+      "ds_write2_b32 v94, v76, v71 offset1:1\n\t"         // {child-block base, t_max}
+      "ds_write_b16 v92, v77\n\t"                         // tag mask
+      "v_lshl_or_b32 v78, 1, v90, v78\n\t"
+      "s_mov_b64 exec, %[sd]\n\t"
+      "v_mul_f32 v90, v56, v72\n\t"
+      "v_pk_mul_f32 v[92:93], v[58:59], v[72:73] op_sel_hi:[1,0]\n\t"
+      "v_add_f32 v90, v90, v84\n\t"                       // centre distances
+      "v_pk_add_f32 v[92:93], v[92:93], v[86:87]\n\t"
+      "v_cmp_gt_f32 vcc, v90, v70\n\t"
+      "v_cmp_gt_f32_e64 %[sb], v92, v70\n\t"
+      "v_cmp_gt_f32_e64 %[sc], v93, v70\n\t"
+      "v_add_u32 v76, v91, v82\n\t"                       // child-block base of the child
+      "v_perm_b32 v77, v89, v89, %[selmask]\n\t"          // its tag mask (big-endian bytes 5..6)
+      "v_cndmask_b32_e64 v90, 0, v72, vcc\n\t"
+      "v_cndmask_b32_e64 v92, 0, v72, %[sb]\n\t"
+      "v_cndmask_b32_e64 v93, 0, v72, %[sc]\n\t"
+      "v_cndmask_b32_e64 v75, 0, 1, %[sc]\n\t"
+      "v_addc_co_u32_e64 v75, %[sf], v75, v75, %[sb]\n\t"
+      "v_addc_co_u32_e64 v75, %[sf], v75, v75, vcc\n\t"   // idx = 4 z + 2 y + x
+      "v_add_f32 v67, v67, v90\n\t"
+      "v_pk_add_f32 v[68:69], v[68:69], v[92:93]\n\t"
+      "v_add_u32 v74, -1, v74\n\t"
+      "v_mov_b32 v73, v85\n\t"                            // h = tc_max
+      "v_mov_b32 v71, v95\n"                              // t_max = tv_max
+      "LnoD%=:\n\t"
+      // ---- ADVANCE (svotrace.comp:329-339)
+      "s_mov_b64 exec, %[sa]\n\t"
+      "s_cbranch_execz LnoA%=\n\t"
+      "v_cmp_le_f32 vcc, v84, v85\n\t"
+      "v_cmp_le_f32_e64 %[sb], v86, v85\n\t"
+      "v_cmp_le_f32_e64 %[sc], v87, v85\n\t"
+      "v_mov_b32 v70, v85\n\t"                            // t_min = tc_max
+      "v_cndmask_b32_e64 v90, 0, v72, vcc\n\t"
+      "v_cndmask_b32_e64 v92, 0, v72, %[sb]\n\t"
+      "v_cndmask_b32_e64 v93, 0, v72, %[sc]\n\t"
+      "v_cndmask_b32_e64 v91, 0, 1, %[sc]\n\t"
+      "v_addc_co_u32_e64 v91, %[sf], v91, v91, %[sb]\n\t"
+      "v_addc_co_u32_e64 v91, %[sf], v91, v91, vcc\n\t"   // step mask
+      "v_sub_f32 v67, v67, v90\n\t"
+      "v_pk_add_f32 v[68:69], v[68:69], v[92:93] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_xor_b32 v75, v75, v91\n\t"
+      "v_and_b32 v91, v75, v91\n\t"
+      "v_cmp_ne_u32 vcc, 0, v91\n\t"                      // left the parent: POP
+      "s_mov_b64 exec, vcc\n\t"
+      "s_cbranch_execz LnoA%=\n\t"
+      // ---- POP (svotrace.comp:341-366)
+      "v_add_f32 v90, v67, v90\n\t"                       // position before the step (exact)
+      "v_pk_add_f32 v[92:93], v[68:69], v[92:93]\n\t"
+      "v_xor_b32 v90, v90, v67\n\t"
+      "v_xor_b32 v91, v92, v68\n\t"
+      "v_bitop3_b32 v90, v90, v93, v69 bitop3:0xf6\n\t"   // a | (b ^ c)
+      "v_or3_b32 v90, v90, v91, 1\n\t"                    // differing bits (| 1 keeps ffbh defined)
+      "v_ffbh_u32 v90, v90\n\t"
+      "v_sub_u32 v94, 20, v90\n\t"                        // scale - 11
+      "v_xor_b32 v74, 31, v90\n\t"                        // scale = 31 - leading zeros
+      "v_lshlrev_b32 v90, 23, v90\n\t"
+      "v_min_u32 v91, 11, v94\n\t"
+      "v_sub_u32 v72, 0x43800000, v90\n\t"                // cell size = 2^(scale - 23)
+      "v_lshl_add_u32 v90, v91, 9, v64\n\t"
+      "v_lshl_add_u32 v91, v91, 7, v65\n\t"
+      "ds_read2_b32 v[92:93], v90 offset1:1\n\t"
+      "ds_read_u16 v91, v91\n\t"
+      "v_bfe_i32 v94, v78, v94, 1\n\t"                    // all ones if this ray pushed that level
+      "v_lshlrev_b32_e64 v95, v74, -1\n\t"
+      "v_mov_b32 v73, 0\n\t"                              // h = 0
+      "v_and_b32 v67, v67, v95\n\t"                       // round the position to the cell
+      "v_and_b32 v68, v68, v95\n\t"
+      "v_and_b32 v69, v69, v95\n\t"
+      "v_bfe_u32 v75, v67, v74, 1\n\t"
+      "v_bfe_u32 v90, v68, v74, 1\n\t"
+      "v_bfe_u32 v95, v69, v74, 1\n\t"
+      "v_lshl_or_b32 v75, v90, 1, v75\n\t"
+      "v_lshl_or_b32 v75, v95, 2, v75\n\t"                // idx from the position bits
+      "v_cmp_le_u32 vcc, 23, v74\n\t"                     // left the octree: MISS
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_and_b32 v76, v94, v92\n\t"
+      "v_and_b32 v71, v94, v93\n\t"
+      "v_and_b32 v77, v94, v91\n\t"
+      "s_cmp_eq_u64 vcc, 0\n\t"
+      "s_cbranch_scc1 LnoA%=\n\t"
+      "s_mov_b64 exec, vcc\n\t"
+      "v_mov_b32 v81, 3\n\t"                              // ST_MISS
+      "s_andn2_b64 %[act], %[act], vcc\n"
+      "LnoA%=:\n\t"
+      "s_bcnt1_i32_b64 %[cnt], %[act]\n\t"
+      "s_cmp_gt_i32 %[cnt], %[thresh]\n\t"
+      "s_cbranch_scc1 Ltrip%=\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      : "+{v67}"(r.px), "+{v[68:69]}"(r.pyz), "+{v70}"(r.t_min), "+{v71}"(r.t_max), "+{v72}"(r.sexp), "+{v73}"(r.h),
+        "+{v74}"(r.scale), "+{v75}"(r.idx), "+{v76}"(r.pbase), "+{v77}"(r.pmask), "+{v78}"(r.written), "+{v79}"(r.iter),
+        "+{v80}"(r.lod_scale), "+{v81}"(status), "+{v82}"(r.cptr), "+{v83}"(r.tag), "+{v88}"(r.rlo), "+{v89}"(r.rhi),
+        [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se),
+        [sf] "=&s"(sf), [cnt] "=&s"(cnt)
+      : "{v56}"(r.cx), "{v57}"(r.bx), "{v[58:59]}"(r.cyz), "{v[60:61]}"(r.byz), "{v62}"(r.octant), "{v63}"(r.cone_t),
+        "{v64}"(lds8), "{v65}"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
+        [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [thresh] "s"(threshold)
+      : "vcc", "scc", "memory", "v84", "v85", "v86", "v87", "v90", "v91", "v92", "v93", "v94", "v95");
+}
+
+}  // namespace svo
