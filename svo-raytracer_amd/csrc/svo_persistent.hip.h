@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         const uint32_t band_total = (uint32_t)band_tiles * 64u;
         uint32_t base = 0;
         if ((int)lane == leader) base = atomicAdd(a.heads + band * kHeadStride, n);
-        base = (uint32_t)__shfl((int)base, leader);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);   // wave-uniform, and the compiler knows it
         const uint32_t slot =
             base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         if (status == ST_IDLE && slot < band_total) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #if SVO_ASM_LOOP && !defined(SVO_STAMPS)
     {
       const unsigned long long act = __ballot(status == ST_ACTIVE);
-      if (act != 0ull) trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold));
+      trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold));
     }
 #else
     for (;;) {

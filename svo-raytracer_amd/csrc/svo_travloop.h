@@ -20,13 +20,10 @@
 // before a VALU reads it as a mask (v_cndmask, v_addc); SALU reads are interlocked.  Loads are
 // counted here (s_waitcnt vmcnt(0) / lgkmcnt(0) inside the block).
 //
-// Registers are pinned (the asm needs both halves and the whole of the y/z pairs):
-//   v56 cx   v57 bx   v[58:59] cy,cz   v[60:61] by,bz   v62 octant   v63 cone_t
-//   v64 &pm[lane]   v65 &mk[lane]
-//   v67 px   v[68:69] py,pz   v70 t_min   v71 t_max   v72 cell size   v73 h   v74 scale
-//   v75 idx  v76 pbase   v77 pmask   v78 written   v79 iter   v80 lod scale   v81 status
-//   v82 cptr v83 tag   v[88:89] record of the last visited child
-//   temporaries v84 tcx  v85 tc_max  v[86:87] tcy,tcz  v90 v91 v[92:93] v94 v95
+// Most operands are allocated by the compiler; the asm needs both the whole and the halves of the
+// y/z pairs, so those are pinned: v[68:69] py,pz; v72 cell size (v[72:73] is the broadcast source of a
+// packed multiply, v73 is scratch); temporaries v[86:87] tcy,tcz, v[92:93]; v[88:89] the record of the
+// last visited child (lanes are masked once they stop, so a hit lane's record stays put).
 #pragma once
 #include "svo_trav.h"
 
@@ -138,47 +135,49 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
   const uint32_t lds2 = lds_offset(&stk.mk[lane]);
   unsigned long long sv, sa, sb, sc, sd, se, sf;
   int cnt;
+  uint32_t t0, t1, t2, t3;
+  float tcx, tcm;
   asm volatile(
       "s_mov_b64 %[sv], exec\n"
       "Ltrip%=:\n\t"
       "s_mov_b64 exec, %[act]\n\t"
       // ---- child slot, iteration cap (svotrace.comp:263-266)
-      "v_xor_b32 v90, v75, v62\n\t"                       // cs = idx ^ octant
-      "v_add_u32 v79, 1, v79\n\t"                         // iter++
-      "v_lshlrev_b32 v91, 1, v90\n\t"                     // 2 cs
-      "v_cmp_lt_u32 vcc, 0x5dc, v79\n\t"                  // iter > 1500
-      "v_lshrrev_b32 v94, 1, v77\n\t"
-      "v_bfe_u32 v83, v77, v91, 2\n\t"                    // tag of the child
-      "v_lshlrev_b32_e64 v91, v91, -1\n\t"                // ~(children below cs)
-      "v_cndmask_b32_e64 v81, v81, 4, vcc\n\t"            // capped lanes: status = ST_CAPPED ...
+      "v_xor_b32 %[t0], %[idx], %[oct]\n\t"                       // cs = idx ^ octant
+      "v_add_u32 %[iter], 1, %[iter]\n\t"                         // iter++
+      "v_lshlrev_b32 %[t1], 1, %[t0]\n\t"                     // 2 cs
+      "v_cmp_lt_u32 vcc, 0x5dc, %[iter]\n\t"                  // iter > 1500
+      "v_lshrrev_b32 %[t2], 1, %[pmask]\n\t"
+      "v_bfe_u32 %[tag], %[pmask], %[t1], 2\n\t"                    // tag of the child
+      "v_lshlrev_b32_e64 %[t1], %[t1], -1\n\t"                // ~(children below cs)
+      "v_cndmask_b32_e64 %[st], %[st], 4, vcc\n\t"            // capped lanes: status = ST_CAPPED ...
       "s_andn2_b64 %[act], %[act], vcc\n\t"               // ... and out of the loop
       "s_andn2_b64 exec, exec, vcc\n\t"
       // byte offset of child cs in its sibling block: 7 cs - 4 popcount(lo) - 2 popcount(both)
-      "v_bitop3_b32 v91, v77, %[k5555], v91 bitop3:0x40\n\t"   // lo = pmask & 0x5555 & below
-      "v_and_b32 v94, v91, v94\n\t"                       // both = lo & (pmask >> 1)
-      "v_bcnt_u32_b32 v94, v94, 0\n\t"
-      "v_bcnt_u32_b32 v94, v91, v94\n\t"
-      "v_bcnt_u32_b32 v94, v91, v94\n\t"                  // popcount(both) + 2 popcount(lo)
-      "v_mad_u32_u24 v82, v90, 7, v76\n\t"
-      "v_mad_i32_i24 v82, v94, -2, v82\n\t"               // cptr
-      "buffer_load_dwordx2 v[88:89], v82, %[rs], 0 offen\n\t"
+      "v_bitop3_b32 %[t1], %[pmask], %[k5555], %[t1] bitop3:0x40\n\t"   // lo = pmask & 0x5555 & below
+      "v_and_b32 %[t2], %[t1], %[t2]\n\t"                       // both = lo & (pmask >> 1)
+      "v_bcnt_u32_b32 %[t2], %[t2], 0\n\t"
+      "v_bcnt_u32_b32 %[t2], %[t1], %[t2]\n\t"
+      "v_bcnt_u32_b32 %[t2], %[t1], %[t2]\n\t"                  // popcount(both) + 2 popcount(lo)
+      "v_mad_u32_u24 %[cptr], %[t0], 7, %[pbase]\n\t"
+      "v_mad_i32_i24 %[cptr], %[t2], -2, %[cptr]\n\t"               // cptr
+      "buffer_load_dwordx2 v[88:89], %[cptr], %[rs], 0 offen\n\t"
       // ---- exit distances of the current cell (svotrace.comp:268-269)
-      "v_mul_f32 v84, v67, v56\n\t"
-      "v_pk_mul_f32 v[86:87], v[68:69], v[58:59]\n\t"
-      "v_cmp_gt_f32 vcc, v70, v63\n\t"                    // t_min > cone_t: cone rays drop to LOD 11 (sticky)
-      "v_sub_f32 v84, v84, v57\n\t"
-      "v_pk_add_f32 v[86:87], v[86:87], v[60:61] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_cmp_le_f32_e64 %[sa], v70, v71\n\t"              // t_min <= t_max
-      "v_cndmask_b32_e64 v80, v80, 12, vcc\n\t"
-      "v_min3_f32 v85, v84, v86, v87\n\t"                 // tc_max
-      "v_min_f32 v95, v71, v85\n\t"                       // tv_max
-      "v_cmp_eq_u32_e64 %[sb], v74, v80\n\t"              // at the LOD scale
-      "v_cmp_le_f32_e64 %[sc], v70, v95\n\t"              // t_min <= tv_max
-      "v_cmp_eq_u32_e64 %[sd], 0, v83\n\t"                // interior tag
+      "v_mul_f32 %[tcx], %[px], %[cx]\n\t"
+      "v_pk_mul_f32 v[86:87], v[68:69], %[cyz]\n\t"
+      "v_cmp_gt_f32 vcc, %[tmin], %[cone]\n\t"                    // t_min > cone_t: cone rays drop to LOD 11 (sticky)
+      "v_sub_f32 %[tcx], %[tcx], %[bx]\n\t"
+      "v_pk_add_f32 v[86:87], v[86:87], %[byz] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_cmp_le_f32_e64 %[sa], %[tmin], %[tmax]\n\t"              // t_min <= t_max
+      "v_cndmask_b32_e64 %[lod], %[lod], 12, vcc\n\t"
+      "v_min3_f32 %[tcm], %[tcx], v86, v87\n\t"                 // tc_max
+      "v_min_f32 %[t3], %[tmax], %[tcm]\n\t"                       // tv_max
+      "v_cmp_eq_u32_e64 %[sb], %[scale], %[lod]\n\t"              // at the LOD scale
+      "v_cmp_le_f32_e64 %[sc], %[tmin], %[t3]\n\t"              // t_min <= tv_max
+      "v_cmp_eq_u32_e64 %[sd], 0, %[tag]\n\t"                // interior tag
       "s_waitcnt vmcnt(0)\n\t"
       "v_cmp_ne_u32_sdwa %[se], v88, %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // value != 0
-      "v_perm_b32 v91, v89, v88, %[selcp]\n\t"            // child pointer (big-endian bytes 1..4)
-      "v_cmp_ne_u32_e64 vcc, 0, v91\n\t"
+      "v_perm_b32 %[t1], v89, v88, %[selcp]\n\t"            // child pointer (big-endian bytes 1..4)
+      "v_cmp_ne_u32_e64 vcc, 0, %[t1]\n\t"
       // lane sets
       "s_and_b64 %[sa], %[sa], %[se]\n\t"                 // N = non-empty and in range
       "s_and_b64 %[sd], %[sd], vcc\n\t"                   // has a child block
@@ -193,116 +192,117 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "s_cmp_eq_u64 %[se], 0\n\t"
       "s_cbranch_scc1 Lnohit%=\n\t"
       "s_mov_b64 exec, %[se]\n\t"
-      "v_mov_b32 v81, 2\n\t"                              // ST_HIT
+      "v_mov_b32 %[st], 2\n\t"                              // ST_HIT
       "s_andn2_b64 %[act], %[act], %[se]\n"
       "Lnohit%=:\n\t"
       // ---- DESCEND (svotrace.comp:291-327)
       "s_mov_b64 exec, %[sd]\n\t"
       "s_cbranch_execz LnoD%=\n\t"
-      "v_cmp_lt_f32 vcc, v85, v73\n\t"                    // tc_max < h: PUSH
+      "v_cmp_lt_f32 vcc, %[tcm], %[h]\n\t"                    // tc_max < h: PUSH
       "v_mul_f32 v72, 0.5, v72\n\t"                       // half
-      "v_add_u32 v90, -11, v74\n\t"
-      "v_min_u32 v90, 11, v90\n\t"                        // stack level
+      "v_add_u32 %[t0], -11, %[scale]\n\t"
+      "v_min_u32 %[t0], 11, %[t0]\n\t"                        // stack level
       "s_and_saveexec_b64 %[sb], vcc\n\t"
-      "v_lshl_add_u32 v94, v90, 9, v64\n\t"
-      "v_lshl_add_u32 v92, v90, 7, v65\n\t"
-      "ds_write2_b32 v94, v76, v71 offset1:1\n\t"         // {child-block base, t_max}
-      "ds_write_b16 v92, v77\n\t"                         // tag mask
-      "v_lshl_or_b32 v78, 1, v90, v78\n\t"
+      "v_lshl_add_u32 %[t2], %[t0], 9, %[lds8]\n\t"
+      "v_lshl_add_u32 v92, %[t0], 7, %[lds2]\n\t"
+      "ds_write2_b32 %[t2], %[pbase], %[tmax] offset1:1\n\t"         // {child-block base, t_max}
+      "ds_write_b16 v92, %[pmask]\n\t"                         // tag mask
+      "v_lshl_or_b32 %[wr], 1, %[t0], %[wr]\n\t"
       "s_mov_b64 exec, %[sd]\n\t"
-      "v_mul_f32 v90, v56, v72\n\t"
-      "v_pk_mul_f32 v[92:93], v[58:59], v[72:73] op_sel_hi:[1,0]\n\t"
-      "v_add_f32 v90, v90, v84\n\t"                       // centre distances
+      "v_mul_f32 %[t0], %[cx], v72\n\t"
+      "v_pk_mul_f32 v[92:93], %[cyz], v[72:73] op_sel_hi:[1,0]\n\t"
+      "v_add_f32 %[t0], %[t0], %[tcx]\n\t"                       // centre distances
       "v_pk_add_f32 v[92:93], v[92:93], v[86:87]\n\t"
-      "v_cmp_gt_f32 vcc, v90, v70\n\t"
-      "v_cmp_gt_f32_e64 %[sb], v92, v70\n\t"
-      "v_cmp_gt_f32_e64 %[sc], v93, v70\n\t"
-      "v_add_u32 v76, v91, v82\n\t"                       // child-block base of the child
-      "v_perm_b32 v77, v89, v89, %[selmask]\n\t"          // its tag mask (big-endian bytes 5..6)
-      "v_cndmask_b32_e64 v90, 0, v72, vcc\n\t"
+      "v_cmp_gt_f32 vcc, %[t0], %[tmin]\n\t"
+      "v_cmp_gt_f32_e64 %[sb], v92, %[tmin]\n\t"
+      "v_cmp_gt_f32_e64 %[sc], v93, %[tmin]\n\t"
+      "v_add_u32 %[pbase], %[t1], %[cptr]\n\t"                       // child-block base of the child
+      "v_perm_b32 %[pmask], v89, v89, %[selmask]\n\t"          // its tag mask (big-endian bytes 5..6)
+      "v_cndmask_b32_e64 %[t0], 0, v72, vcc\n\t"
       "v_cndmask_b32_e64 v92, 0, v72, %[sb]\n\t"
       "v_cndmask_b32_e64 v93, 0, v72, %[sc]\n\t"
-      "v_cndmask_b32_e64 v75, 0, 1, %[sc]\n\t"
-      "v_addc_co_u32_e64 v75, %[sf], v75, v75, %[sb]\n\t"
-      "v_addc_co_u32_e64 v75, %[sf], v75, v75, vcc\n\t"   // idx = 4 z + 2 y + x
-      "v_add_f32 v67, v67, v90\n\t"
+      "v_cndmask_b32_e64 %[idx], 0, 1, %[sc]\n\t"
+      "v_addc_co_u32_e64 %[idx], %[sf], %[idx], %[idx], %[sb]\n\t"
+      "v_addc_co_u32_e64 %[idx], %[sf], %[idx], %[idx], vcc\n\t"   // idx = 4 z + 2 y + x
+      "v_add_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[68:69], v[68:69], v[92:93]\n\t"
-      "v_add_u32 v74, -1, v74\n\t"
-      "v_mov_b32 v73, v85\n\t"                            // h = tc_max
-      "v_mov_b32 v71, v95\n"                              // t_max = tv_max
+      "v_add_u32 %[scale], -1, %[scale]\n\t"
+      "v_mov_b32 %[h], %[tcm]\n\t"                            // h = tc_max
+      "v_mov_b32 %[tmax], %[t3]\n"                              // t_max = tv_max
       "LnoD%=:\n\t"
       // ---- ADVANCE (svotrace.comp:329-339)
       "s_mov_b64 exec, %[sa]\n\t"
       "s_cbranch_execz LnoA%=\n\t"
-      "v_cmp_le_f32 vcc, v84, v85\n\t"
-      "v_cmp_le_f32_e64 %[sb], v86, v85\n\t"
-      "v_cmp_le_f32_e64 %[sc], v87, v85\n\t"
-      "v_mov_b32 v70, v85\n\t"                            // t_min = tc_max
-      "v_cndmask_b32_e64 v90, 0, v72, vcc\n\t"
+      "v_cmp_le_f32 vcc, %[tcx], %[tcm]\n\t"
+      "v_cmp_le_f32_e64 %[sb], v86, %[tcm]\n\t"
+      "v_cmp_le_f32_e64 %[sc], v87, %[tcm]\n\t"
+      "v_mov_b32 %[tmin], %[tcm]\n\t"                            // t_min = tc_max
+      "v_cndmask_b32_e64 %[t0], 0, v72, vcc\n\t"
       "v_cndmask_b32_e64 v92, 0, v72, %[sb]\n\t"
       "v_cndmask_b32_e64 v93, 0, v72, %[sc]\n\t"
-      "v_cndmask_b32_e64 v91, 0, 1, %[sc]\n\t"
-      "v_addc_co_u32_e64 v91, %[sf], v91, v91, %[sb]\n\t"
-      "v_addc_co_u32_e64 v91, %[sf], v91, v91, vcc\n\t"   // step mask
-      "v_sub_f32 v67, v67, v90\n\t"
+      "v_cndmask_b32_e64 %[t1], 0, 1, %[sc]\n\t"
+      "v_addc_co_u32_e64 %[t1], %[sf], %[t1], %[t1], %[sb]\n\t"
+      "v_addc_co_u32_e64 %[t1], %[sf], %[t1], %[t1], vcc\n\t"   // step mask
+      "v_sub_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[68:69], v[68:69], v[92:93] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_xor_b32 v75, v75, v91\n\t"
-      "v_and_b32 v91, v75, v91\n\t"
-      "v_cmp_ne_u32 vcc, 0, v91\n\t"                      // left the parent: POP
+      "v_xor_b32 %[idx], %[idx], %[t1]\n\t"
+      "v_and_b32 %[t1], %[idx], %[t1]\n\t"
+      "v_cmp_ne_u32 vcc, 0, %[t1]\n\t"                      // left the parent: POP
       "s_mov_b64 exec, vcc\n\t"
       "s_cbranch_execz LnoA%=\n\t"
       // ---- POP (svotrace.comp:341-366)
-      "v_add_f32 v90, v67, v90\n\t"                       // position before the step (exact)
+      "v_add_f32 %[t0], %[px], %[t0]\n\t"                       // position before the step (exact)
       "v_pk_add_f32 v[92:93], v[68:69], v[92:93]\n\t"
-      "v_xor_b32 v90, v90, v67\n\t"
-      "v_xor_b32 v91, v92, v68\n\t"
-      "v_bitop3_b32 v90, v90, v93, v69 bitop3:0xf6\n\t"   // a | (b ^ c)
-      "v_or3_b32 v90, v90, v91, 1\n\t"                    // differing bits (| 1 keeps ffbh defined)
-      "v_ffbh_u32 v90, v90\n\t"
-      "v_sub_u32 v94, 20, v90\n\t"                        // scale - 11
-      "v_xor_b32 v74, 31, v90\n\t"                        // scale = 31 - leading zeros
-      "v_lshlrev_b32 v90, 23, v90\n\t"
-      "v_min_u32 v91, 11, v94\n\t"
-      "v_sub_u32 v72, 0x43800000, v90\n\t"                // cell size = 2^(scale - 23)
-      "v_lshl_add_u32 v90, v91, 9, v64\n\t"
-      "v_lshl_add_u32 v91, v91, 7, v65\n\t"
-      "ds_read2_b32 v[92:93], v90 offset1:1\n\t"
-      "ds_read_u16 v91, v91\n\t"
-      "v_bfe_i32 v94, v78, v94, 1\n\t"                    // all ones if this ray pushed that level
-      "v_lshlrev_b32_e64 v95, v74, -1\n\t"
-      "v_mov_b32 v73, 0\n\t"                              // h = 0
-      "v_and_b32 v67, v67, v95\n\t"                       // round the position to the cell
-      "v_and_b32 v68, v68, v95\n\t"
-      "v_and_b32 v69, v69, v95\n\t"
-      "v_bfe_u32 v75, v67, v74, 1\n\t"
-      "v_bfe_u32 v90, v68, v74, 1\n\t"
-      "v_bfe_u32 v95, v69, v74, 1\n\t"
-      "v_lshl_or_b32 v75, v90, 1, v75\n\t"
-      "v_lshl_or_b32 v75, v95, 2, v75\n\t"                // idx from the position bits
-      "v_cmp_le_u32 vcc, 23, v74\n\t"                     // left the octree: MISS
+      "v_xor_b32 %[t0], %[t0], %[px]\n\t"
+      "v_xor_b32 %[t1], v92, v68\n\t"
+      "v_bitop3_b32 %[t0], %[t0], v93, v69 bitop3:0xf6\n\t"   // a | (b ^ c)
+      "v_or3_b32 %[t0], %[t0], %[t1], 1\n\t"                    // differing bits (| 1 keeps ffbh defined)
+      "v_ffbh_u32 %[t0], %[t0]\n\t"
+      "v_sub_u32 %[t2], 20, %[t0]\n\t"                        // scale - 11
+      "v_xor_b32 %[scale], 31, %[t0]\n\t"                        // scale = 31 - leading zeros
+      "v_lshlrev_b32 %[t0], 23, %[t0]\n\t"
+      "v_min_u32 %[t1], 11, %[t2]\n\t"
+      "v_sub_u32 v72, 0x43800000, %[t0]\n\t"                // cell size = 2^(scale - 23)
+      "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
+      "v_lshl_add_u32 %[t1], %[t1], 7, %[lds2]\n\t"
+      "ds_read2_b32 v[92:93], %[t0] offset1:1\n\t"
+      "ds_read_u16 %[t1], %[t1]\n\t"
+      "v_bfe_i32 %[t2], %[wr], %[t2], 1\n\t"                    // all ones if this ray pushed that level
+      "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
+      "v_mov_b32 %[h], 0\n\t"                              // h = 0
+      "v_and_b32 %[px], %[px], %[t3]\n\t"                       // round the position to the cell
+      "v_and_b32 v68, v68, %[t3]\n\t"
+      "v_and_b32 v69, v69, %[t3]\n\t"
+      "v_bfe_u32 %[idx], %[px], %[scale], 1\n\t"
+      "v_bfe_u32 %[t0], v68, %[scale], 1\n\t"
+      "v_bfe_u32 %[t3], v69, %[scale], 1\n\t"
+      "v_lshl_or_b32 %[idx], %[t0], 1, %[idx]\n\t"
+      "v_lshl_or_b32 %[idx], %[t3], 2, %[idx]\n\t"                // idx from the position bits
+      "v_cmp_le_u32 vcc, 23, %[scale]\n\t"                     // left the octree: MISS
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_and_b32 v76, v94, v92\n\t"
-      "v_and_b32 v71, v94, v93\n\t"
-      "v_and_b32 v77, v94, v91\n\t"
+      "v_and_b32 %[pbase], %[t2], v92\n\t"
+      "v_and_b32 %[tmax], %[t2], v93\n\t"
+      "v_and_b32 %[pmask], %[t2], %[t1]\n\t"
       "s_cmp_eq_u64 vcc, 0\n\t"
       "s_cbranch_scc1 LnoA%=\n\t"
       "s_mov_b64 exec, vcc\n\t"
-      "v_mov_b32 v81, 3\n\t"                              // ST_MISS
+      "v_mov_b32 %[st], 3\n\t"                              // ST_MISS
       "s_andn2_b64 %[act], %[act], vcc\n"
       "LnoA%=:\n\t"
       "s_bcnt1_i32_b64 %[cnt], %[act]\n\t"
       "s_cmp_gt_i32 %[cnt], %[thresh]\n\t"
       "s_cbranch_scc1 Ltrip%=\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
-      : "+{v67}"(r.px), "+{v[68:69]}"(r.pyz), "+{v70}"(r.t_min), "+{v71}"(r.t_max), "+{v72}"(r.sexp), "+{v73}"(r.h),
-        "+{v74}"(r.scale), "+{v75}"(r.idx), "+{v76}"(r.pbase), "+{v77}"(r.pmask), "+{v78}"(r.written), "+{v79}"(r.iter),
-        "+{v80}"(r.lod_scale), "+{v81}"(status), "+{v82}"(r.cptr), "+{v83}"(r.tag), "+{v88}"(r.rlo), "+{v89}"(r.rhi),
-        [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se),
-        [sf] "=&s"(sf), [cnt] "=&s"(cnt)
-      : "{v56}"(r.cx), "{v57}"(r.bx), "{v[58:59]}"(r.cyz), "{v[60:61]}"(r.byz), "{v62}"(r.octant), "{v63}"(r.cone_t),
-        "{v64}"(lds8), "{v65}"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
+      : [px] "+v"(r.px), "+{v[68:69]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v72}"(r.sexp), [h] "+v"(r.h),
+        [scale] "+v"(r.scale), [idx] "+v"(r.idx), [pbase] "+v"(r.pbase), [pmask] "+v"(r.pmask), [wr] "+v"(r.written),
+        [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [cptr] "+v"(r.cptr), [tag] "+v"(r.tag),
+        "={v88}"(r.rlo), "={v89}"(r.rhi), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        [t3] "=&v"(t3), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd),
+        [se] "=&s"(se), [sf] "=&s"(sf), [cnt] "=&s"(cnt)
+      : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [cone] "v"(r.cone_t),
+        [lds8] "v"(lds8), [lds2] "v"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
         [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [thresh] "s"(threshold)
-      : "vcc", "scc", "memory", "v84", "v85", "v86", "v87", "v90", "v91", "v92", "v93", "v94", "v95");
+      : "vcc", "scc", "memory", "v73", "v86", "v87", "v92", "v93");
 }
 
 }  // namespace svo
