@@ -149,9 +149,9 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_lshrrev_b32 %[t2], 1, %[pmask]\n\t"
       "v_bfe_u32 %[tag], %[pmask], %[t1], 2\n\t"                    // tag of the child
       "v_lshlrev_b32_e64 %[t1], %[t1], -1\n\t"                // ~(children below cs)
-      "v_cndmask_b32_e64 %[st], %[st], 4, vcc\n\t"            // capped lanes: status = ST_CAPPED ...
-      "s_andn2_b64 %[act], %[act], vcc\n\t"               // ... and out of the loop
-      "s_andn2_b64 exec, exec, vcc\n\t"
+      "s_cmp_lg_u64 vcc, 0\n\t"
+      "s_cbranch_scc1 Lcap%=\n"                          // rare, out of line
+      "Lnocap%=:\n\t"
       // byte offset of child cs in its sibling block: 7 cs - 4 popcount(lo) - 2 popcount(both)
       "v_bitop3_b32 %[t1], %[pmask], %[k5555], %[t1] bitop3:0x40\n\t"   // lo = pmask & 0x5555 & below
       "v_and_b32 %[t2], %[t1], %[t2]\n\t"                       // both = lo & (pmask >> 1)
@@ -160,7 +160,10 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_bcnt_u32_b32 %[t2], %[t1], %[t2]\n\t"                  // popcount(both) + 2 popcount(lo)
       "v_mad_u32_u24 %[cptr], %[t0], 7, %[pbase]\n\t"
       "v_mad_i32_i24 %[cptr], %[t2], -2, %[cptr]\n\t"               // cptr
-      "buffer_load_dwordx2 v[88:89], %[cptr], %[rs], 0 offen\n\t"
+      // two dword loads: the texture path takes 96 cycles per CU for a wave of misaligned, divergent dwordx2 and
+      // 34 for a dword of any alignment (tools/calib_td.hip)
+      "buffer_load_dword v88, %[cptr], %[rs], 0 offen\n\t"
+      "buffer_load_dword v89, %[cptr], %[rs], 0 offen offset:4\n\t"
       // ---- exit distances of the current cell (svotrace.comp:268-269)
       "v_mul_f32 %[tcx], %[px], %[cx]\n\t"
       "v_pk_mul_f32 v[86:87], v[68:69], %[cyz]\n\t"
@@ -181,20 +184,16 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       // lane sets
       "s_and_b64 %[sa], %[sa], %[se]\n\t"                 // N = non-empty and in range
       "s_and_b64 %[sd], %[sd], vcc\n\t"                   // has a child block
-      "s_andn2_b64 %[se], %[sc], %[sd]\n\t"
-      "s_or_b64 %[se], %[se], %[sb]\n\t"
-      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // HIT = N & (at LOD | (inside & no child block))
+      "s_or_b64 %[se], %[sb], %[sc]\n\t"
+      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // N & (at LOD | inside): hits or descends
       "s_and_b64 %[sd], %[sd], %[sc]\n\t"
       "s_andn2_b64 %[sd], %[sd], %[sb]\n\t"
       "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = N & !at LOD & inside & child block
-      "s_or_b64 %[sa], %[se], %[sd]\n\t"
-      "s_andn2_b64 %[sa], exec, %[sa]\n\t"                // ADVANCE = the rest
-      "s_cmp_eq_u64 %[se], 0\n\t"
-      "s_cbranch_scc1 Lnohit%=\n\t"
+      "s_andn2_b64 %[sa], exec, %[se]\n\t"                // ADVANCE = the rest
+      "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = N & (at LOD | (inside & no child block))
       "s_mov_b64 exec, %[se]\n\t"
       "v_mov_b32 %[st], 2\n\t"                              // ST_HIT
-      "s_andn2_b64 %[act], %[act], %[se]\n"
-      "Lnohit%=:\n\t"
+      "s_andn2_b64 %[act], %[act], %[se]\n\t"
       // ---- DESCEND (svotrace.comp:291-327)
       "s_mov_b64 exec, %[sd]\n\t"
       "s_cbranch_execz LnoD%=\n\t"
@@ -260,9 +259,8 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_ffbh_u32 %[t0], %[t0]\n\t"
       "v_sub_u32 %[t2], 20, %[t0]\n\t"                        // scale - 11
       "v_xor_b32 %[scale], 31, %[t0]\n\t"                        // scale = 31 - leading zeros
-      "v_lshlrev_b32 %[t0], 23, %[t0]\n\t"
       "v_min_u32 %[t1], 11, %[t2]\n\t"
-      "v_sub_u32 v72, 0x43800000, %[t0]\n\t"                // cell size = 2^(scale - 23)
+      "v_lshl_add_u32 v72, %[scale], 23, %[kexp]\n\t"        // cell size = 2^(scale - 23)
       "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
       "v_lshl_add_u32 %[t1], %[t1], 7, %[lds2]\n\t"
       "ds_read2_b32 v[92:93], %[t0] offset1:1\n\t"
@@ -283,15 +281,25 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_and_b32 %[pbase], %[t2], v92\n\t"
       "v_and_b32 %[tmax], %[t2], v93\n\t"
       "v_and_b32 %[pmask], %[t2], %[t1]\n\t"
-      "s_cmp_eq_u64 vcc, 0\n\t"
-      "s_cbranch_scc1 LnoA%=\n\t"
-      "s_mov_b64 exec, vcc\n\t"
-      "v_mov_b32 %[st], 3\n\t"                              // ST_MISS
-      "s_andn2_b64 %[act], %[act], vcc\n"
+      "s_cmp_lg_u64 vcc, 0\n\t"
+      "s_cbranch_scc1 Lmiss%=\n"                         // out of line
       "LnoA%=:\n\t"
       "s_bcnt1_i32_b64 %[cnt], %[act]\n\t"
       "s_cmp_gt_i32 %[cnt], %[thresh]\n\t"
       "s_cbranch_scc1 Ltrip%=\n\t"
+      "s_branch Lend%=\n"
+      "Lcap%=:\n\t"                                       // iteration cap: status = ST_CAPPED, lane out of the loop
+      "s_mov_b64 exec, vcc\n\t"
+      "v_mov_b32 %[st], 4\n\t"
+      "s_andn2_b64 %[act], %[act], vcc\n\t"
+      "s_mov_b64 exec, %[act]\n\t"
+      "s_branch Lnocap%=\n"
+      "Lmiss%=:\n\t"                                      // left the octree: status = ST_MISS
+      "s_mov_b64 exec, vcc\n\t"
+      "v_mov_b32 %[st], 3\n\t"
+      "s_andn2_b64 %[act], %[act], vcc\n\t"
+      "s_branch LnoA%=\n"
+      "Lend%=:\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
       : [px] "+v"(r.px), "+{v[68:69]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v72}"(r.sexp), [h] "+v"(r.h),
         [scale] "+v"(r.scale), [idx] "+v"(r.idx), [pbase] "+v"(r.pbase), [pmask] "+v"(r.pmask), [wr] "+v"(r.written),
@@ -301,7 +309,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
         [se] "=&s"(se), [sf] "=&s"(sf), [cnt] "=&s"(cnt)
       : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [cone] "v"(r.cone_t),
         [lds8] "v"(lds8), [lds2] "v"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
-        [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [thresh] "s"(threshold)
+        [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
       : "vcc", "scc", "memory", "v73", "v86", "v87", "v92", "v93");
 }
 
