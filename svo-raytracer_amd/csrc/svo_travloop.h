@@ -133,7 +133,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
                                           int &status, unsigned long long act, const int threshold) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
   const uint32_t lds2 = lds_offset(&stk.mk[lane]);
-  unsigned long long sv, sa, sb, sc, sd, se, sf;
+  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh;
   int cnt;
   uint32_t t0, t1, t2, t3;
   float tcx, tcm;
@@ -177,6 +177,17 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_cmp_eq_u32_e64 %[sb], %[scale], %[lod]\n\t"              // at the LOD scale
       "v_cmp_le_f32_e64 %[sc], %[tmin], %[t3]\n\t"              // t_min <= tv_max
       "v_cmp_eq_u32_e64 %[sd], 0, %[tag]\n\t"                // interior tag
+      // the ADVANCE step of every active lane, computed while the record is in flight (it does not depend on the
+      // record); lanes that turn out to hit or descend simply do not commit it
+      "v_cmp_le_f32 vcc, %[tcx], %[tcm]\n\t"
+      "v_cmp_le_f32_e64 %[sg], v86, %[tcm]\n\t"
+      "v_cmp_le_f32_e64 %[sh], v87, %[tcm]\n\t"
+      "v_cndmask_b32_e64 %[t0], 0, v72, vcc\n\t"            // per-axis decrement: the cell size or 0
+      "v_cndmask_b32_e64 v92, 0, v72, %[sg]\n\t"
+      "v_cndmask_b32_e64 v93, 0, v72, %[sh]\n\t"
+      "v_cndmask_b32_e64 %[t2], 0, 1, %[sh]\n\t"
+      "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], %[sg]\n\t"
+      "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], vcc\n\t"   // step mask
       "s_waitcnt vmcnt(0)\n\t"
       "v_cmp_ne_u32_sdwa %[se], v88, %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // value != 0
       "v_perm_b32 %[t1], v89, v88, %[selcp]\n\t"            // child pointer (big-endian bytes 1..4)
@@ -202,9 +213,9 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_add_u32 %[t0], -11, %[scale]\n\t"
       "v_min_u32 %[t0], 11, %[t0]\n\t"                        // stack level
       "s_and_saveexec_b64 %[sb], vcc\n\t"
-      "v_lshl_add_u32 %[t2], %[t0], 9, %[lds8]\n\t"
+      "v_lshl_add_u32 v93, %[t0], 9, %[lds8]\n\t"
       "v_lshl_add_u32 v92, %[t0], 7, %[lds2]\n\t"
-      "ds_write2_b32 %[t2], %[pbase], %[tmax] offset1:1\n\t"         // {child-block base, t_max}
+      "ds_write2_b32 v93, %[pbase], %[tmax] offset1:1\n\t"         // {child-block base, t_max}
       "ds_write_b16 v92, %[pmask]\n\t"                         // tag mask
       "v_lshl_or_b32 %[wr], 1, %[t0], %[wr]\n\t"
       "s_mov_b64 exec, %[sd]\n\t"
@@ -232,21 +243,12 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       // ---- ADVANCE (svotrace.comp:329-339)
       "s_mov_b64 exec, %[sa]\n\t"
       "s_cbranch_execz LnoA%=\n\t"
-      "v_cmp_le_f32 vcc, %[tcx], %[tcm]\n\t"
-      "v_cmp_le_f32_e64 %[sb], v86, %[tcm]\n\t"
-      "v_cmp_le_f32_e64 %[sc], v87, %[tcm]\n\t"
       "v_mov_b32 %[tmin], %[tcm]\n\t"                            // t_min = tc_max
-      "v_cndmask_b32_e64 %[t0], 0, v72, vcc\n\t"
-      "v_cndmask_b32_e64 v92, 0, v72, %[sb]\n\t"
-      "v_cndmask_b32_e64 v93, 0, v72, %[sc]\n\t"
-      "v_cndmask_b32_e64 %[t1], 0, 1, %[sc]\n\t"
-      "v_addc_co_u32_e64 %[t1], %[sf], %[t1], %[t1], %[sb]\n\t"
-      "v_addc_co_u32_e64 %[t1], %[sf], %[t1], %[t1], vcc\n\t"   // step mask
       "v_sub_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[68:69], v[68:69], v[92:93] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_xor_b32 %[idx], %[idx], %[t1]\n\t"
-      "v_and_b32 %[t1], %[idx], %[t1]\n\t"
-      "v_cmp_ne_u32 vcc, 0, %[t1]\n\t"                      // left the parent: POP
+      "v_xor_b32 %[idx], %[idx], %[t2]\n\t"
+      "v_and_b32 %[t2], %[idx], %[t2]\n\t"
+      "v_cmp_ne_u32 vcc, 0, %[t2]\n\t"                      // left the parent: POP
       "s_mov_b64 exec, vcc\n\t"
       "s_cbranch_execz LnoA%=\n\t"
       // ---- POP (svotrace.comp:341-366)
@@ -306,7 +308,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [cptr] "+v"(r.cptr), [tag] "+v"(r.tag),
         "={v88}"(r.rlo), "={v89}"(r.rhi), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
         [t3] "=&v"(t3), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd),
-        [se] "=&s"(se), [sf] "=&s"(sf), [cnt] "=&s"(cnt)
+        [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh), [cnt] "=&s"(cnt)
       : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [cone] "v"(r.cone_t),
         [lds8] "v"(lds8), [lds2] "v"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
         [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
