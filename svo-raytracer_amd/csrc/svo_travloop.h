@@ -188,20 +188,22 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_cndmask_b32_e64 %[t2], 0, 1, %[sh]\n\t"
       "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], %[sg]\n\t"
       "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], vcc\n\t"   // step mask
+      // lane sets, the part that does not need the record (scalar unit, overlaps the load)
+      "s_or_b64 %[se], %[sb], %[sc]\n\t"
+      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // in range & (at LOD | inside): hits or descends if not empty
+      "s_and_b64 %[sd], %[sd], %[sc]\n\t"
+      "s_andn2_b64 %[sd], %[sd], %[sb]\n\t"
+      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // in range & !at LOD & inside & interior tag: descends if it has a child block
       "s_waitcnt vmcnt(0)\n\t"
-      "v_cmp_ne_u32_sdwa %[se], v88, %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // value != 0
+      "v_cmp_ne_u32_sdwa %[sa], v88, %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // value != 0
       "v_perm_b32 %[t1], v89, v88, %[selcp]\n\t"            // child pointer (big-endian bytes 1..4)
       "v_cmp_ne_u32_e64 vcc, 0, %[t1]\n\t"
       // lane sets
-      "s_and_b64 %[sa], %[sa], %[se]\n\t"                 // N = non-empty and in range
-      "s_and_b64 %[sd], %[sd], vcc\n\t"                   // has a child block
-      "s_or_b64 %[se], %[sb], %[sc]\n\t"
-      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // N & (at LOD | inside): hits or descends
-      "s_and_b64 %[sd], %[sd], %[sc]\n\t"
-      "s_andn2_b64 %[sd], %[sd], %[sb]\n\t"
-      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = N & !at LOD & inside & child block
+      "s_and_b64 %[sd], %[sd], vcc\n\t"
+      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = not empty & in range & !at LOD & inside & child block
+      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // not empty & in range & (at LOD | inside)
       "s_andn2_b64 %[sa], exec, %[se]\n\t"                // ADVANCE = the rest
-      "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = N & (at LOD | (inside & no child block))
+      "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = not empty & in range & (at LOD | (inside & no child block))
       "s_mov_b64 exec, %[se]\n\t"
       "v_mov_b32 %[st], 2\n\t"                              // ST_HIT
       "s_andn2_b64 %[act], %[act], %[se]\n\t"
