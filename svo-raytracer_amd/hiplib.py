@@ -30,16 +30,21 @@ class Stats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-_lib = None
+# the same library built with hipcc's translation of the traversal loop instead of the assembly one
+# (csrc/Makefile target `cxxloop`); only the cross-check test loads it
+CXXLOOP_LIB_PATH = os.path.join(_HERE, "csrc", "libsvohip_cxxloop.so")
+
+_libs = {}
 
 
-def lib():
-    global _lib
+def lib(path=None):
+    path = path or LIB_PATH
+    _lib = _libs.get(path)
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"HIP library missing: {LIB_PATH} (run __graft_entry__.build()); "
+        if not os.path.exists(path):
+            raise RuntimeError(f"HIP library missing: {path} (run __graft_entry__.build()); "
                                "the SVO hot path has no CPU fallback")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
         fp = ctypes.POINTER(ctypes.c_float)
         L.svo_create.argtypes = [ci, ctypes.POINTER(vp)]
@@ -75,7 +80,7 @@ def lib():
         for n in EXPORTS:
             if n != "svo_last_error":
                 getattr(L, n).restype = ci
-        _lib = L
+        _lib = _libs[path] = L
     return _lib
 
 
@@ -88,8 +93,8 @@ class SvoError(RuntimeError):
 class HipContext:
     """One context per GPU (include/svo_hip.h)."""
 
-    def __init__(self, device=0):
-        self._L = lib()
+    def __init__(self, device=0, lib_path=None):
+        self._L = lib(lib_path)
         self._h = ctypes.c_void_p()
         rc = self._L.svo_create(int(device), ctypes.byref(self._h))
         if rc != 0:

@@ -279,3 +279,33 @@ def test_empty_pool_matches_oracle(ctx):
             assert (got["rgba"] == ref["rgba"]).all(), (pipeline, mode)
             assert (got["depth"].view(np.uint32) == ref["depth"].view(np.uint32)).all()
             assert (got["hits"]["iter"] == ref["hits"]["iter"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_asm_loop_equals_cxx_loop(ctx, mode):
+    """The hand-written gfx950 traversal loop (csrc/svo_travloop.h) against hipcc's translation of the readable
+    trav_step() (csrc/svo_trav.h, library built with -DSVO_ASM_LOOP=0): every output of a full-HD frame, bit for bit,
+    including iteration counts -- on a regular camera, on one with NaN components and on one outside the cube."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    if not os.path.exists(hiplib.CXXLOOP_LIB_PATH):
+        pytest.fail("libsvohip_cxxloop.so missing: run __graft_entry__.build()")
+    other = hiplib.HipContext(0, lib_path=hiplib.CXXLOOP_LIB_PATH)
+    try:
+        pool, _ = scene.build_scene(2048)
+        nan_cam = np.array(CAMERAS["K1"], dtype=np.float32).copy()
+        nan_cam[3] = np.nan                          # l1.x: a fan of rays with one NaN direction component
+        far_cam = np.array(CAMERAS["K0"], dtype=np.float32).copy()
+        far_cam[0:3] = (3.5, 1.25, 2.75)             # outside the cube: misses, grazing entries
+        ctx.set_pipeline(1)
+        other.set_pipeline(1)
+        for cam in (CAMERAS["K1"], CAMERAS["K2"], nan_cam, far_cam):
+            a = ctx.render(pool, 1920, 1080, cam, 7, mode, bounces=3)
+            b = other.render(pool, 1920, 1080, cam, 7, mode, bounces=3)
+            assert np.array_equal(a["rgba"], b["rgba"])
+            assert np.array_equal(a["depth"].view(np.uint32), b["depth"].view(np.uint32))
+            assert a["hits"].tobytes() == b["hits"].tobytes()
+    finally:
+        other.close()
