@@ -41,6 +41,7 @@ struct PersistArgs {
   size_t npix;
   uint32_t *heads;   // 8 band counters (pixel slots drawn so far)
   int tiles_per_band;
+  int rows_per_band;   // tile rows per XCD band (SVO_BAND_COLMAJOR)
   int sample;
   int thresh_num;    // a round starts once active lanes <= thresh_num/8 of those active at its start
 };
@@ -82,6 +83,9 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
 #define SVO_TRAV_RESULT trav_result
 #endif
 
+#ifndef SVO_BAND_COLMAJOR
+#define SVO_BAND_COLMAJOR 1
+#endif
 #ifndef SVO_PERSIST_WAVES_PER_SIMD
 #define SVO_PERSIST_WAVES_PER_SIMD 5
 #endif
@@ -207,22 +211,37 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
       if (idle != 0ull) {
         const uint32_t n = (uint32_t)__builtin_popcountll(idle);
         const int leader = __builtin_ctzll(idle);
+#if SVO_BAND_COLMAJOR
+        // a band = a strip of whole tile rows, walked column by column: the pixels in flight on an XCD form a compact
+        // block of the screen (strip height x a few dozen tile columns) instead of two or three full-width tile rows
+        const int first_row = (int)band * a.rows_per_band;
+        int band_rows = f.tiles_y - first_row;
+        band_rows = band_rows < 0 ? 0 : (band_rows > a.rows_per_band ? a.rows_per_band : band_rows);
+        const uint32_t band_total = (uint32_t)(band_rows * f.tiles_x) * 64u;
+#else
         const int first_tile = (int)band * a.tiles_per_band;
         int band_tiles = f.ntiles - first_tile;
         band_tiles = band_tiles < 0 ? 0 : (band_tiles > a.tiles_per_band ? a.tiles_per_band : band_tiles);
         const uint32_t band_total = (uint32_t)band_tiles * 64u;
+#endif
         uint32_t base = 0;
         if ((int)lane == leader) base = atomicAdd(a.heads + band * kHeadStride, n);
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);   // wave-uniform, and the compiler knows it
         const uint32_t slot =
             base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         if (status == ST_IDLE && slot < band_total) {
-          const int tile = first_tile + (int)(slot >> 6);
           const uint32_t l = slot & 63u;
-          px = (tile % f.tiles_x) * 8 + (int)(l & 7u);
-          py = frame_gy(f, tile / f.tiles_x, (int)(l >> 3));
+#if SVO_BAND_COLMAJOR
+          const int j = (int)(slot >> 6);
+          const int tile_x = j / band_rows, tile_y = first_row + j % band_rows;
+#else
+          const int tile = first_tile + (int)(slot >> 6);
+          const int tile_x = tile % f.tiles_x, tile_y = tile / f.tiles_x;
+#endif
+          px = tile_x * 8 + (int)(l & 7u);
+          py = frame_gy(f, tile_y, (int)(l >> 3));
           if (px < f.width && py < f.y1 && py < f.height) {
-            pix = (uint32_t)frame_oy(f, tile / f.tiles_x, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
+            pix = (uint32_t)frame_oy(f, tile_y, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
             d = primary_direction(f, px, py);
             seg = 0u;
             mask = mk(1.f, 1.f, 1.f);
@@ -348,6 +367,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   PersistArgs a;
   a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = b.facc; a.npix = npix;
   a.tiles_per_band = (f.ntiles + 7) / 8;
+  a.rows_per_band = (f.tiles_y + 7) / 8;
   a.thresh_num = b.thresh_num;
   const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
   for (int s = 0; s < spp; s++) {
