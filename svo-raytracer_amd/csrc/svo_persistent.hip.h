@@ -11,10 +11,13 @@
 // (pipeline 2) the bounce ray starts where its primary just warmed the caches, no path
 // state travels through HBM and the frame has one tail instead of one per stage.
 //
-// Work distribution: the tile list is cut into 8 contiguous bands, one per XCD (each XCD
-// has its own 4 MiB L2; neighbouring tiles walk the same subtrees).  A wave reads its XCD
+// Work distribution: the frame is cut into 8 strips of whole tile rows, one per XCD (each XCD
+// has its own 4 MiB L2; neighbouring tiles walk the same subtrees), and a strip is walked column
+// by column so that the pixels an XCD has in flight form a compact block.  A wave reads its XCD
 // id from the hardware register and draws from that band's counter, then steals from the
-// other bands.  Placement is only a locality hint: any wave may render any pixel.
+// other bands.  Consecutive launches walk the columns in opposite directions (a frame starts
+// where the previous one is finishing).  Placement is only a locality hint: any wave may render
+// any pixel.
 #pragma once
 #include "svo_fused.hip.h"
 #include "svo_trav.h"
@@ -42,6 +45,7 @@ struct PersistArgs {
   uint32_t *heads;   // 8 band counters (pixel slots drawn so far)
   int tiles_per_band;
   int rows_per_band;   // tile rows per XCD band (SVO_BAND_COLMAJOR)
+  int reverse;         // walk the columns right to left (every other launch)
   int sample;
   int thresh_num;    // a round starts once active lanes <= thresh_num/8 of those active at its start
 };
@@ -85,6 +89,9 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
 
 #ifndef SVO_BAND_COLMAJOR
 #define SVO_BAND_COLMAJOR 1
+#endif
+#ifndef SVO_SERPENTINE
+#define SVO_SERPENTINE 1
 #endif
 #ifndef SVO_PERSIST_WAVES_PER_SIMD
 #define SVO_PERSIST_WAVES_PER_SIMD 5
@@ -233,7 +240,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
           const uint32_t l = slot & 63u;
 #if SVO_BAND_COLMAJOR
           const int j = (int)(slot >> 6);
-          const int tile_x = j / band_rows, tile_y = first_row + j % band_rows;
+          int tile_x = j / band_rows;
+          const int tile_y = first_row + j % band_rows;
+          if (a.reverse) tile_x = f.tiles_x - 1 - tile_x;   // serpentine: this frame ends where the next one starts
 #else
           const int tile = first_tile + (int)(slot >> 6);
           const int tile_x = tile % f.tiles_x, tile_y = tile / f.tiles_x;
@@ -372,6 +381,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
   for (int s = 0; s < spp; s++) {
     // a ring of counter sets: frames may be in flight on different streams at the same time
+    a.reverse = SVO_SERPENTINE ? (int)(b.launches & 1u) : 0;
     a.heads = b.heads + (size_t)(b.launches++ % kHeadSets) * kHeadWords;
     if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
