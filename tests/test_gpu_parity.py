@@ -309,3 +309,35 @@ def test_asm_loop_equals_cxx_loop(ctx, mode):
             assert a["hits"].tobytes() == b["hits"].tobytes()
     finally:
         other.close()
+
+
+@pytest.mark.gpu
+def test_asm_loop_equals_cxx_loop_under_varied_occupancy(ctx):
+    """Same cross-check, repeated with different numbers of persistent waves per CU, refill thresholds and frame
+    numbers: a missed wait state or an unwaited load in the assembly would show up as a rare, load-dependent mismatch."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    other = hiplib.HipContext(0, lib_path=hiplib.CXXLOOP_LIB_PATH)
+    try:
+        pool, _ = scene.build_scene(2048)
+        ctx.set_pipeline(1)
+        other.set_pipeline(1)
+        ctx.pool_upload(pool)
+        other.pool_upload(pool)
+        ref = {}
+        for k, (waves, thresh) in enumerate([(1, 3), (2, 6), (4, 4), (7, 5), (10, 5), (13, 2), (16, 7), (20, 4), (0, 0)] * 2):
+            frame = 2 + (k % 5)
+            mode = (0, 2)[k % 2]
+            ctx.set_tuning(waves, thresh)
+            a = ctx.render(None, 1280, 720, CAMERAS["K1"], frame, mode, bounces=3)
+            key = (frame, mode)
+            if key not in ref:
+                ref[key] = other.render(None, 1280, 720, CAMERAS["K1"], frame, mode, bounces=3)
+            b = ref[key]
+            assert np.array_equal(a["rgba"], b["rgba"]), (waves, thresh, frame, mode)
+            assert np.array_equal(a["depth"].view(np.uint32), b["depth"].view(np.uint32)), (waves, thresh, frame, mode)
+            assert a["hits"].tobytes() == b["hits"].tobytes(), (waves, thresh, frame, mode)
+    finally:
+        ctx.set_tuning(0, 0)
+        other.close()
