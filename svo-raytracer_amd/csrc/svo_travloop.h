@@ -2,16 +2,20 @@
 //
 // trav_loop() runs trav_step() (svo_trav.h, the readable statement of the same arithmetic) on
 // the wave's active lanes until no more than `threshold` of them are still traversing.  The
-// instruction stream is the kernel's critical resource: a wave64 VALU instruction holds its
-// SIMD for 4 cycles and every trip executes the descend, advance and pop sections one after the
-// other for whichever lanes need them, so the frame time is proportional to the number of
-// vector instructions in this loop.  hipcc's version of the loop is 123 vector instructions per
-// trip (phi copies on the back edge, status bookkeeping in a VGPR, hazard nops); this one is 98:
+// instruction stream is the kernel's critical resource: a wave issues one instruction every ~5
+// cycles, a SIMD retires a wave64 VALU instruction every ~2.5 (tools/calib_valu.hip), and every
+// trip executes the descend, advance and pop sections one after the other for whichever lanes
+// need them.  hipcc's version of the loop is 123 vector instructions per trip (phi copies on the
+// back edge, status bookkeeping in a VGPR, hazard nops); this one is 103:
 //   * lane sets (active / hit / descend / advance / pop) live in SGPR pairs and are combined
-//     on the scalar unit; the status VGPR is only written when a lane stops;
+//     on the scalar unit, the record-independent part before the wait; the status VGPR is only
+//     written when a lane stops; the rare exits (iteration cap, leaving the octree) are out of line;
 //   * the three per-axis comparisons feed carry chains (v_addc_co_u32) that build the 3-bit
 //     child index, and selected increments (0 or the cell size) that update the position in
 //     place -- no old/new copies of the position;
+//   * the advance step of every active lane is computed while the record is in flight;
+//   * the record comes in two dword loads (34 cycles each in the texture path for a divergent
+//     wave, any alignment) instead of one misaligned dwordx2 (96 cycles, tools/calib_td.hip);
 //   * the pushed {child-block base, t_max} pair goes to LDS with one ds_write2_b32 from the two
 //     registers where they live.
 // Arithmetic, operand order and rounding are those of trav_step(); the parity tests run both.
