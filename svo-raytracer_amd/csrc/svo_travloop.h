@@ -6,7 +6,7 @@
 // cycles, a SIMD retires a wave64 VALU instruction every ~2.5 (tools/calib_valu.hip), and every
 // trip executes the descend, advance and pop sections one after the other for whichever lanes
 // need them.  hipcc's version of the loop is 123 vector instructions per trip (phi copies on the
-// back edge, status bookkeeping in a VGPR, hazard nops); this one is 103:
+// back edge, status bookkeeping in a VGPR, hazard nops); this one is 100 (+ 29 scalar / branch):
 //   * lane sets (active / hit / descend / advance / pop) live in SGPR pairs and are combined
 //     on the scalar unit, the record-independent part before the wait; the status VGPR is only
 //     written when a lane stops; the rare exits (iteration cap, leaving the octree) are out of line;
