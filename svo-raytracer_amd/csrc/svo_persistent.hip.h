@@ -77,7 +77,7 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
 #ifndef SVO_ASM_LOOP
 #define SVO_ASM_LOOP 1
 #endif
-#if SVO_ASM_LOOP && !defined(SVO_STAMPS)
+#if SVO_ASM_LOOP
 #define SVO_TRAV_T TravRegs
 #define SVO_TRAV_INIT trav_init_regs
 #define SVO_TRAV_RESULT trav_result_regs
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
     // (a fixed "N lanes free" trigger was tried instead of the proportional one: 3 % slower at its best setting)
     const int threshold = __builtin_amdgcn_readfirstlane(bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0);
-#if SVO_ASM_LOOP && !defined(SVO_STAMPS)
+#if SVO_ASM_LOOP
     {
       const unsigned long long act = __ballot(status == ST_ACTIVE);
       trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold));

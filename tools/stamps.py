@@ -18,5 +18,9 @@ for wpc in (4, 8, 12, 16, 20):
     L.svo_debug_heads(ctx._h, buf.ctypes.data)
     d = buf[0:12].view(np.uint64)
     nw = 256 * wpc
+    if d[3] == 0:   # assembly loop: trips are not counted inside the asm block
+        print("waves/cu", wpc, "thresh", t, "ms %.3f" % ms[-1], "rounds/wave %.1f  cyc/round: shade %.0f + refill+init %.0f + traversal %.0f" % (
+            d[2] / nw, d[4] / max(d[2], 1), (d[0] - d[4]) / max(d[2], 1), d[1] / max(d[2], 1)))
+        continue
     print("waves/cu", wpc, "thresh", t, "ms %.3f" % ms[-1], "rounds/wave %.1f trips/wave %.1f  cyc/round %.0f (shade %.0f, refill+init %.0f)  cyc/trip %.0f (of which load issue->data %.0f)" % (
         d[2] / nw, d[3] / nw, d[0] / max(d[2], 1), d[4] / max(d[2], 1), (d[0] - d[4]) / max(d[2], 1), d[1] / max(d[3], 1), d[5] / max(d[3], 1)))
