@@ -112,8 +112,8 @@ def main():
     ctx.set_params(2, args.mode, nbytes, 0, args.bounces, 0, 1)  # frameNumber 2 = first frame (Main.java:16,275)
     ctx.set_pipeline(args.pipeline)
     if args.pipeline == 1 and max(2 if use_comm else 1, args.inflight) > 1:
-        ctx.set_tuning(10, 5)  # several frames in flight share the CUs: 10 persistent waves per CU and frame,
-                               # rounds once 3/8 of the traversing lanes have stopped (swept on MI355X)
+        ctx.set_tuning(10, 9)  # several frames in flight share the CUs: 10 persistent waves per CU and frame,
+                               # rounds once 7/16 of the traversing lanes have stopped (swept on MI355X, tools/sweep*.sh)
     # rank r renders tile rows r, r + N, r + 2N, ... (interleaved: every rank sees the same mix of near and
     # far terrain) and stores them packed in its band of the gather buffer
     s_first, s_step, s_n, s_out0, rows_per_rank = stripe_layout(H_total, world, rank)

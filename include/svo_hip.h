@@ -111,8 +111,8 @@ int svo_set_stripes(svo_ctx *ctx, int first_tile_row, int tile_row_step, int n_t
 int svo_set_pipeline(svo_ctx *ctx, int pipeline);
 /* pipeline-1 launch shape: persistent waves per CU (0 = fill the GPU: right for one frame at a time;
  * about 10 when the caller keeps 2-3 frames in flight on alternating streams) and the refill round
- * threshold in eighths (0 = default 4: a round starts once half the traversing lanes have stopped) */
-int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_eighths);
+ * threshold in sixteenths (0 = default 9: a round starts once 7/16 of the traversing lanes have stopped) */
+int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_sixteenths);
 /* record per-pixel svo_hit (costs 16 B/pixel of stores); default on */
 int svo_set_hit_records(svo_ctx *ctx, int enabled);
 

@@ -283,13 +283,13 @@ int svo_set_pipeline(svo_ctx *c, int pipeline) {
   return SVO_OK;
 }
 
-int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_eighths) {
-  if (!c || waves_per_cu < 0 || round_threshold_eighths < 0 || round_threshold_eighths > 7)
+int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_sixteenths) {
+  if (!c || waves_per_cu < 0 || round_threshold_sixteenths < 0 || round_threshold_sixteenths > 15)
     return fail(c, SVO_E_INVALID, "svo_set_tuning: bad values");
   c->pb.waves_per_cu = waves_per_cu;
-  c->pb.thresh_num = round_threshold_eighths ? round_threshold_eighths : 4;
+  c->pb.thresh_num = round_threshold_sixteenths ? round_threshold_sixteenths : 9;
   c->wf.waves_per_cu = waves_per_cu;
-  c->wf.thresh_num = round_threshold_eighths ? round_threshold_eighths : 6;
+  c->wf.thresh_num = round_threshold_sixteenths ? round_threshold_sixteenths : 12;
   return SVO_OK;
 }
 

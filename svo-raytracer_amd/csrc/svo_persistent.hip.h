@@ -47,7 +47,7 @@ struct PersistArgs {
   int rows_per_band;   // tile rows per XCD band (SVO_BAND_COLMAJOR)
   int reverse;         // walk the columns right to left (every other launch)
   int sample;
-  int thresh_num;    // a round starts once active lanes <= thresh_num/8 of those active at its start
+  int thresh_num;    // a round starts once active lanes <= thresh_num/16 of those active at its start
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     // ---------------- traverse until enough lanes have stopped to make a round worthwhile
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
     // (a fixed "N lanes free" trigger was tried instead of the proportional one: 3 % slower at its best setting)
-    const int threshold = __builtin_amdgcn_readfirstlane(bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0);
+    const int threshold = __builtin_amdgcn_readfirstlane(bands_left > 0 ? (active0 * a.thresh_num) / 16 : 0);
 #if SVO_ASM_LOOP
     {
       const unsigned long long act = __ballot(status == ST_ACTIVE);
@@ -316,7 +316,7 @@ struct PersistBuffers {
   float *facc = nullptr;
   size_t npix = 0;
   int blocks = 0;
-  int thresh_num = 4;
+  int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/sweep8.sh)
   int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
   int max_per_cu = 16, cus = 256;
   unsigned launches = 0;

@@ -44,7 +44,7 @@ struct WavefrontBuffers {
   size_t npix = 0, slots = 0;
   int blocks = 0;
   unsigned launches = 0;
-  int waves_per_cu = 0, thresh_num = 6;
+  int waves_per_cu = 0, thresh_num = 12;   // sixteenths
   int max_per_cu = 16, cus = 256;
 };
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64, SVO_TRACE_WAVES_PER_SIMD) void wf_trace_kernel(
       break;
     }
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
-    const int threshold = bands_left > 0 ? (active0 * a.thresh_num) / 8 : 0;
+    const int threshold = bands_left > 0 ? (active0 * a.thresh_num) / 16 : 0;
     for (;;) {
 #ifdef SVO_STAMPS
       { unsigned long long dummy = 0; if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t, dummy); }

@@ -169,8 +169,8 @@ class HipContext:
     def set_pipeline(self, p):
         self._chk(self._L.svo_set_pipeline(self._h, int(p)))
 
-    def set_tuning(self, waves_per_cu=0, round_threshold_eighths=0):
-        self._chk(self._L.svo_set_tuning(self._h, int(waves_per_cu), int(round_threshold_eighths)))
+    def set_tuning(self, waves_per_cu=0, round_threshold_sixteenths=0):
+        self._chk(self._L.svo_set_tuning(self._h, int(waves_per_cu), int(round_threshold_sixteenths)))
 
     def set_hit_records(self, on):
         self._chk(self._L.svo_set_hit_records(self._h, 1 if on else 0))

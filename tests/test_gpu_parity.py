@@ -326,7 +326,7 @@ def test_asm_loop_equals_cxx_loop_under_varied_occupancy(ctx):
         ctx.pool_upload(pool)
         other.pool_upload(pool)
         ref = {}
-        for k, (waves, thresh) in enumerate([(1, 3), (2, 6), (4, 4), (7, 5), (10, 5), (13, 2), (16, 7), (20, 4), (0, 0)] * 2):
+        for k, (waves, thresh) in enumerate([(1, 6), (2, 12), (4, 8), (7, 10), (10, 9), (13, 4), (16, 15), (20, 8), (0, 0)] * 2):
             frame = 2 + (k % 5)
             mode = (0, 2)[k % 2]
             ctx.set_tuning(waves, thresh)

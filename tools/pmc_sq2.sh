@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ-side counters of the persistent kernel at the bench tuning (waves/CU 10, threshold 5/8), one frame at a time
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-export SVO_PERSIST_THRESH=5 SVO_PERSIST_WAVES_PER_CU=${WAVES:-10}
+export SVO_PERSIST_THRESH=9 SVO_PERSIST_WAVES_PER_CU=${WAVES:-10}
 ARGS="--steps 30 --warmup 3 --cpu-seconds 0 --inflight 1"
 i=0
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \

@@ -10,7 +10,7 @@ ctx.pool_upload(pool); ctx.resize(1920, 1080); ctx.set_camera(CAMERAS["K1"]); ct
 L = hiplib.lib()
 L.svo_debug_heads.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 for wpc in (4, 8, 12, 16, 20):
-    t = 5
+    t = 9
     ctx.set_tuning(wpc, t)
     ctx.set_params(2, 0, 0, 0, 2, 0, 1)
     ms = ctx.time_frames(2, 1)   # 3 launches -> ring slots k, k+1, k+2; read all, take the last launch's set
