@@ -15,6 +15,15 @@
  *     it never retains a caller pointer across calls.
  *   - a context is bound to one GPU and is not re-entrant (the reference drives GL from
  *     the single thread that owns the context, Window.java:40).
+ *   - ordering: svo_dispatch_async only enqueues.  A caller that alternates streams (svo_set_stream)
+ *     to keep frames in flight orders its own output buffers; the library orders everything it owns:
+ *     per-frame work counters and sample accumulators are re-used only after the frame that used
+ *     them has finished (GPU-side event waits), and every call that changes or moves the pool or the
+ *     library's images (svo_pool_upload / _update / _reserve / _upload_device, svo_resize,
+ *     svo_destroy) first waits for the whole device, so a frame in flight on any stream sees the
+ *     pool either before or after the edit, never torn.
+ *   - pools of up to 13 levels (the reference's MAX_DEPTH, "up to 8192^3") are supported; on deeper
+ *     pools rays that descend below level 13 re-use the deepest stack slot.
  *   - the pool bytes are taken exactly as Octree.getByteBuffer() holds them
  *     (Octree.java:68-176); no re-encoding happens at the boundary.
  */
@@ -142,6 +151,10 @@ int svo_time_frames(svo_ctx *ctx, int warmup, int iters, float *ms);
 int svo_read_color(svo_ctx *ctx, void *rgba8);
 int svo_read_depth(svo_ctx *ctx, float *depth);
 int svo_read_hits(svo_ctx *ctx, svo_hit *hits);
+/* one pixel of the three images: what Main.updateEarly actually needs from its full-frame glGetTexImage
+ * (Main.java:132-146 reads the 8.3 MB depth image to pick depth[540][960], the crosshair).  Any of
+ * rgba8 (4 bytes) / depth / hit may be NULL.  Library-owned or bound outputs; waits for the context's stream. */
+int svo_read_pixel(svo_ctx *ctx, int x, int y, void *rgba8, float *depth, svo_hit *hit);
 /* render into caller-owned device buffers (e.g. torch tensors that an RCCL all-gather then
  * reads in place): color = u32 rgba8 [rows][W], depth = f32, hits = svo_hit (may be NULL ->
  * hit records off).  Pixel (x, y) lands at element y*W + x, so the buffers must cover every

@@ -48,6 +48,9 @@ jint Java_src_engine_HipRenderer_nDispatch(void *env, void *cls, jlong ctx);
 jint Java_src_engine_HipRenderer_nReadColor(void *env, void *cls, jlong ctx, jlong addr);
 jint Java_src_engine_HipRenderer_nReadDepth(void *env, void *cls, jlong ctx, jlong addr);
 jint Java_src_engine_HipRenderer_nReadHits(void *env, void *cls, jlong ctx, jlong addr);
+/* the crosshair pick of Main.java:132-146 without the full-frame readback: addresses of 4 / 4 / 16 bytes, 0 = skip */
+jint Java_src_engine_HipRenderer_nReadPixel(void *env, void *cls, jlong ctx, jint x, jint y, jlong rgba_addr,
+                                            jlong depth_addr, jlong hit_addr);
 
 #ifdef __cplusplus
 }

@@ -149,6 +149,18 @@ public class HipRenderer {
     check(nReadHits(ctx, MemoryUtil.memAddress(hits)));
   }
 
+  /**
+   * The crosshair pick of Main.updateEarly (Main.java:132-146) without the full-frame readback:
+   * depth of one pixel.  Main reads depth[540][960] of the previous frame every frame.
+   */
+  public float readDepthPixel(int x, int y) {
+    ByteBuffer one = MemoryUtil.memAlloc(4);
+    check(nReadPixel(ctx, x, y, 0L, MemoryUtil.memAddress(one), 0L));
+    float d = one.getFloat(0);
+    MemoryUtil.memFree(one);
+    return d;
+  }
+
   /** Dormant shader features (svotrace.comp:444, 500-504, 668-670); defaults = live behaviour. */
   public void setPathOptions(int bounces, int mirrorMask, int spp) {
     this.bounces = bounces;
@@ -176,4 +188,5 @@ public class HipRenderer {
   private static native int nReadColor(long ctx, long addr);
   private static native int nReadDepth(long ctx, long addr);
   private static native int nReadHits(long ctx, long addr);
+  private static native int nReadPixel(long ctx, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);
 }

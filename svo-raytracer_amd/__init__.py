@@ -6,4 +6,4 @@ Only what the hot path needs lives here:
   scene/   deterministic procedural SVO scene generator (reference pool layout)
   *.py     thin ctypes bindings used by tests/ and bench.py
 """
-__all__ = ["scene", "hiplib", "renderer", "camera", "octree", "tiles"]
+__all__ = ["scene", "hiplib", "hostlib", "cameras", "tiles"]

@@ -245,13 +245,14 @@ __device__ __forceinline__ Cast cast_ray(const Pool &pool, WaveStack &stk, const
       if (t_min <= tv_max) {
         const uint32_t ccp = tag == 0u ? rec_cp(rec) : 0u;
         if (ccp == 0u) { hit = true; break; }
-        if (tc_max < h) {  // PUSH
-          const int lv = scale - kStackBase;
-          if (lv >= 0 && lv < kStackLevels) {
-            stk.pm[lv * 64 + lane] = make_uint2(pbase, __float_as_uint(t_max));
-            stk.mk[lv * 64 + lane] = (uint16_t)pmask;
-            written |= 1u << lv;
-          }
+        if (tc_max < h) {  // PUSH.  scale is 11..22 for pools of up to 13 levels (the supported depth, = the
+          // reference's MAX_DEPTH); the clamp only keeps LDS accesses in range on deeper pools, and is the same in
+          // all three pipelines (trav_step, trav_loop) so that they keep producing identical bytes there too
+          const uint32_t lvu = (uint32_t)(scale - kStackBase);
+          const uint32_t lv = lvu < (uint32_t)(kStackLevels - 1) ? lvu : (uint32_t)(kStackLevels - 1);
+          stk.pm[lv * 64 + lane] = make_uint2(pbase, __float_as_uint(t_max));
+          stk.mk[lv * 64 + lane] = (uint16_t)pmask;
+          written |= 1u << lv;
         }
         h = tc_max;
         pbase = cptr + ccp;

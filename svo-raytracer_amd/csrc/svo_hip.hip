@@ -122,7 +122,7 @@ static int ensure_pool_capacity(svo_ctx *c, uint64_t need_len, bool keep) {
   if (keep && c->d_pool && c->pool_len)
     HIPCHK(c, hipMemcpyAsync(np, c->d_pool, c->pool_len, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->d_pool) HIPCHK(c, hipFree(c->d_pool));
+  if (c->d_pool) HIPCHK(c, hipFree(c->d_pool));   // callers have synchronised the device: no frame still reads it
   c->d_pool = np;
   c->pool_cap = ncap;
   return SVO_OK;
@@ -138,6 +138,7 @@ static int refresh_dword0(svo_ctx *c) {
 int svo_pool_reserve(svo_ctx *c, uint64_t nbytes) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
   int rc = ensure_pool_capacity(c, nbytes, false);
   if (rc) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_pool, 0, c->pool_cap, c->stream));
@@ -161,7 +162,9 @@ int svo_pool_upload_device(svo_ctx *c, const void *dptr, uint64_t nbytes) {
 int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
   if (!c || (!host && nbytes)) return fail(c, SVO_E_INVALID, "svo_pool_upload: null buffer");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // frames may be in flight on any stream the caller has handed over (svo_set_stream): the pool changes only
+  // when the whole device is idle, so a frame sees either the old bytes or the new ones, never a mix
+  HIPCHK(c, hipDeviceSynchronize());
   int rc = ensure_pool_capacity(c, nbytes, false);
   if (rc) return rc;
   if (nbytes) HIPCHK(c, hipMemcpy(c->d_pool, host, nbytes, hipMemcpyHostToDevice));
@@ -176,7 +179,7 @@ int svo_pool_update(svo_ctx *c, const void *host_base, uint64_t start, uint64_t 
   if (start >= end) return fail(c, SVO_E_INVALID, "Update SSBO error: Invalid parameters.");
   if (!c->d_pool) return fail(c, SVO_E_NOPOOL, "svo_pool_update before svo_pool_upload");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipDeviceSynchronize());   // see svo_pool_upload
   if (end > c->pool_len) {
     int rc = ensure_pool_capacity(c, end, true);
     if (rc) return rc;
@@ -192,7 +195,7 @@ int svo_pool_download(svo_ctx *c, void *host, uint64_t nbytes) {
   if (!c->d_pool) return fail(c, SVO_E_NOPOOL, "no pool");
   if (nbytes > c->pool_len) nbytes = c->pool_len;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(host, c->d_pool, nbytes, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
@@ -231,7 +234,7 @@ int svo_resize(svo_ctx *c, int width, int height) {
   if (!c || width <= 0 || height <= 0) return fail(c, SVO_E_INVALID, "svo_resize: bad size");
   HIPCHK(c, hipSetDevice(c->device));
   if (width == c->width && height == c->height && c->own_color) return SVO_OK;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipDeviceSynchronize());   // frames in flight on other streams still write the old images
   free_outputs(c);
   const size_t n = (size_t)width * (size_t)height;
   HIPCHK(c, hipMalloc((void **)&c->own_color, n * 4));
@@ -331,7 +334,26 @@ static int make_frame(svo_ctx *c, Frame &f) {
   f.tiles_y = c->n_tile_rows < 0 ? (f.y1 - f.y0 + 7) / 8 : c->n_tile_rows;
   f.ntiles = f.tiles_x * f.tiles_y;
   f.write_hits = (c->write_hits && c->d_hits) ? 1 : 0;
+  if (!c->external_outputs && c->n_tile_rows > 0) {
+    // packed stripes land at output rows out_y0 + 8 j + ly: they must stay inside the library's W x H images
+    // (caller-owned gather buffers are the caller's to size, see svo_bind_outputs)
+    int last = -1;
+    for (int j = c->n_tile_rows - 1; j >= 0; j--)
+      if ((long long)f.y0 + (long long)j * 8 * f.row_step < (long long)f.height) { last = j; break; }
+    if (last >= 0) {
+      const int gy = f.y0 + last * 8 * f.row_step;
+      const int rows = std::min(8, f.height - gy);
+      if (f.out_y0 + last * 8 + rows > f.height)
+        return fail(c, SVO_E_INVALID, "svo_set_stripes: packed stripes do not fit the library-owned images; bind "
+                                      "caller-owned outputs that cover out_row0 + 8 * n_tile_rows rows");
+    }
+  }
   return SVO_OK;
+}
+
+// elements per output plane that a launch of `f` may index
+static size_t out_elems(const svo_ctx *c, const Frame &f) {
+  return std::max((size_t)c->width * (size_t)c->height, (size_t)(f.out_y0 + f.tiles_y * 8) * (size_t)c->width);
 }
 
 static int launch_frame(svo_ctx *c, bool count) {
@@ -341,14 +363,12 @@ static int launch_frame(svo_ctx *c, bool count) {
   if (f.ntiles <= 0) return SVO_OK;
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
   if (c->pipeline == 1 && !count) {
-    rc = persist_launch(c->pb, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, c->stream);
+    rc = persist_launch(c->pb, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, out_elems(c, f), c->stream);
     if (rc) return fail(c, SVO_E_HIP, std::string("persistent pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
   if (c->pipeline == 2 && !count) {
-    const size_t out_npix = std::max((size_t)c->width * (size_t)c->height,
-                                     (size_t)(f.out_y0 + f.tiles_y * 8) * (size_t)c->width);
-    rc = wavefront_launch(c->wf, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, out_npix, c->stream);
+    rc = wavefront_launch(c->wf, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, out_elems(c, f), c->stream);
     if (rc) return fail(c, SVO_E_HIP, std::string("wavefront pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
@@ -414,21 +434,24 @@ int svo_get_stats(svo_ctx *c, svo_stats *out) {
 int svo_time_frames(svo_ctx *c, int warmup, int iters, float *ms) {
   if (!c || iters <= 0 || !ms) return fail(c, SVO_E_INVALID, "svo_time_frames: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
-  for (int i = 0; i < warmup; i++) {
-    int rc = launch_frame(c, false);
-    if (rc) return rc;
+  std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
+  int rc = SVO_OK;
+  hipError_t e = hipSuccess;
+  const char *what = "";
+  auto ok = [&](hipError_t r, const char *w) { if (r != hipSuccess && e == hipSuccess) { e = r; what = w; } return r == hipSuccess; };
+  for (int i = 0; i < warmup && rc == SVO_OK; i++) rc = launch_frame(c, false);
+  for (size_t i = 0; i < ev.size() && rc == SVO_OK && e == hipSuccess; i++) ok(hipEventCreate(&ev[i]), "hipEventCreate");
+  if (rc == SVO_OK && e == hipSuccess) ok(hipEventRecord(ev[0], c->stream), "hipEventRecord");
+  for (int i = 0; i < iters && rc == SVO_OK && e == hipSuccess; i++) {
+    rc = launch_frame(c, false);
+    if (rc == SVO_OK) ok(hipEventRecord(ev[(size_t)i + 1], c->stream), "hipEventRecord");
   }
-  std::vector<hipEvent_t> ev((size_t)iters + 1);
-  for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
-  HIPCHK(c, hipEventRecord(ev[0], c->stream));
-  for (int i = 0; i < iters; i++) {
-    int rc = launch_frame(c, false);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(ev[(size_t)i + 1], c->stream));
-  }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < iters; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], ev[(size_t)i], ev[(size_t)i + 1]));
-  for (auto &e : ev) (void)hipEventDestroy(e);
+  (void)hipStreamSynchronize(c->stream);   // also on the error paths: the events must be idle before they go
+  for (int i = 0; i < iters && rc == SVO_OK && e == hipSuccess; i++)
+    ok(hipEventElapsedTime(&ms[i], ev[(size_t)i], ev[(size_t)i + 1]), "hipEventElapsedTime");
+  for (auto &x : ev) if (x) (void)hipEventDestroy(x);
+  if (rc != SVO_OK) return rc;
+  if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
   c->stats.last_dispatch_ms = ms[iters - 1];
   return SVO_OK;
 }
@@ -445,6 +468,22 @@ static int read_rows(svo_ctx *c, void *dst, const void *src, size_t elem) {
 int svo_read_color(svo_ctx *c, void *rgba8) { return c ? read_rows(c, rgba8, c->d_color, 4) : SVO_E_INVALID; }
 int svo_read_depth(svo_ctx *c, float *depth) { return c ? read_rows(c, depth, c->d_depth, 4) : SVO_E_INVALID; }
 int svo_read_hits(svo_ctx *c, svo_hit *hits) { return c ? read_rows(c, hits, c->d_hits, 16) : SVO_E_INVALID; }
+
+int svo_read_pixel(svo_ctx *c, int x, int y, void *rgba8, float *depth, svo_hit *hit) {
+  if (!c) return SVO_E_INVALID;
+  if (x < 0 || y < 0 || x >= c->width || y >= c->height) return fail(c, SVO_E_INVALID, "svo_read_pixel: outside the image");
+  if (!c->d_color) return fail(c, SVO_E_INVALID, "readback before svo_resize");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t o = (size_t)y * (size_t)c->width + (size_t)x;
+  if (rgba8) HIPCHK(c, hipMemcpy(rgba8, c->d_color + o, 4, hipMemcpyDeviceToHost));
+  if (depth) HIPCHK(c, hipMemcpy(depth, c->d_depth + o, 4, hipMemcpyDeviceToHost));
+  if (hit) {
+    if (!c->d_hits) return fail(c, SVO_E_INVALID, "svo_read_pixel: no hit image bound");
+    HIPCHK(c, hipMemcpy(hit, c->d_hits + o, 16, hipMemcpyDeviceToHost));
+  }
+  return SVO_OK;
+}
 
 int svo_output_device_ptrs(svo_ctx *c, void **color, void **depth, void **hits) {
   if (!c) return SVO_E_INVALID;

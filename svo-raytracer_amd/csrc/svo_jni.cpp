@@ -48,5 +48,10 @@ jint Java_src_engine_HipRenderer_nReadDepth(void *, void *, jlong ctx, jlong add
 jint Java_src_engine_HipRenderer_nReadHits(void *, void *, jlong ctx, jlong addr) {
   return svo_read_hits((svo_ctx *)(intptr_t)ctx, (svo_hit *)(intptr_t)addr);
 }
+jint Java_src_engine_HipRenderer_nReadPixel(void *, void *, jlong ctx, jint x, jint y, jlong rgba_addr, jlong depth_addr,
+                                            jlong hit_addr) {
+  return svo_read_pixel((svo_ctx *)(intptr_t)ctx, x, y, (void *)(intptr_t)rgba_addr, (float *)(intptr_t)depth_addr,
+                        (svo_hit *)(intptr_t)hit_addr);
+}
 
 }  // extern "C"

@@ -311,22 +311,35 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #endif
 }
 
+constexpr int kHeadSets = 8;   // counter sets: one per launch, reused round-robin
+constexpr int kFaccSets = 4;   // colour-sum buffers (spp > 1): one per frame, reused round-robin
+
 struct PersistBuffers {
   uint32_t *heads = nullptr;
-  float *facc = nullptr;
+  // a counter set / colour-sum buffer may still be in use by a frame in flight on another stream when the ring
+  // comes round: the launch that re-uses it first waits (on the GPU, hipStreamWaitEvent) for the event its
+  // previous user recorded
+  hipEvent_t head_done[kHeadSets] = {};
+  bool head_used[kHeadSets] = {};
+  float *facc[kFaccSets] = {};
+  hipEvent_t facc_done[kFaccSets] = {};
+  bool facc_used[kFaccSets] = {};
   size_t npix = 0;
   int blocks = 0;
   int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/sweep8.sh)
   int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
   int max_per_cu = 16, cus = 256;
-  unsigned launches = 0;
+  unsigned launches = 0, frames = 0;
 };
-constexpr int kHeadSets = 8;
 
 inline void persist_free(PersistBuffers &b) {
   if (b.heads) (void)hipFree(b.heads);
-  if (b.facc) (void)hipFree(b.facc);
+  for (auto &f : b.facc) if (f) (void)hipFree(f);
+  for (auto &e : b.head_done) if (e) (void)hipEventDestroy(e);
+  for (auto &e : b.facc_done) if (e) (void)hipEventDestroy(e);
+  const int wpc = b.waves_per_cu, th = b.thresh_num;   // tuning survives a resize
   b = PersistBuffers();
+  b.waves_per_cu = wpc; b.thresh_num = th;
 }
 
 template <int kMode>
@@ -345,12 +358,18 @@ __global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t 
   color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
 }
 
+// `out_npix` = elements of the output images: W*H, or more when packed stripes overhang the frame (caller-owned
+// gather buffers); the colour-sum planes are indexed like the outputs.
 inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f, uint32_t *color, float *depth,
-                          uint4 *hits, hipStream_t stream) {
-  const size_t npix = (size_t)f.width * (size_t)f.height;
+                          uint4 *hits, size_t out_npix, hipStream_t stream) {
+  const size_t npix = out_npix;
   hipError_t e;
   if (!b.heads) {
     if ((e = hipMalloc((void **)&b.heads, kHeadSets * kHeadWords * sizeof(uint32_t))) != hipSuccess) return (int)e;
+    for (auto &ev : b.head_done)
+      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    for (auto &ev : b.facc_done)
+      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
     int dev = 0, cus = 256, per_cu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -367,14 +386,25 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     b.blocks = b.cus * per_cu;
   }
   const int spp = f.spp < 1 ? 1 : f.spp;
-  if (spp > 1 && b.npix != npix) {
-    if (b.facc) (void)hipFree(b.facc);
-    b.facc = nullptr;
-    if ((e = hipMalloc((void **)&b.facc, npix * 3 * sizeof(float))) != hipSuccess) return (int)e;
-    b.npix = npix;
+  float *facc = nullptr;
+  int fset = 0;
+  if (spp > 1) {
+    if (b.npix < npix) {   // grow: nothing may still be summing into the old planes
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
+      for (int i = 0; i < kFaccSets; i++) {
+        if (b.facc[i]) (void)hipFree(b.facc[i]);
+        b.facc[i] = nullptr;
+        b.facc_used[i] = false;
+        if ((e = hipMalloc((void **)&b.facc[i], npix * 3 * sizeof(float))) != hipSuccess) return (int)e;
+      }
+      b.npix = npix;
+    }
+    fset = (int)(b.frames++ % kFaccSets);
+    facc = b.facc[fset];
+    if (b.facc_used[fset] && (e = hipStreamWaitEvent(stream, b.facc_done[fset], 0)) != hipSuccess) return (int)e;
   }
   PersistArgs a;
-  a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = b.facc; a.npix = npix;
+  a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = facc; a.npix = b.npix;
   a.tiles_per_band = (f.ntiles + 7) / 8;
   a.rows_per_band = (f.tiles_y + 7) / 8;
   a.thresh_num = b.thresh_num;
@@ -382,7 +412,9 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   for (int s = 0; s < spp; s++) {
     // a ring of counter sets: frames may be in flight on different streams at the same time
     a.reverse = SVO_SERPENTINE ? (int)(b.launches & 1u) : 0;
-    a.heads = b.heads + (size_t)(b.launches++ % kHeadSets) * kHeadWords;
+    const int hset = (int)(b.launches++ % kHeadSets);
+    a.heads = b.heads + (size_t)hset * kHeadWords;
+    if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
     switch (f.render_mode) {
@@ -393,11 +425,15 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
       default: persist_launch_mode<4>(a, blocks, stream); break;
     }
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    if ((e = hipEventRecord(b.head_done[hset], stream)) != hipSuccess) return (int)e;
+    b.head_used[hset] = true;
   }
   if (spp > 1) {
     dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8));
-    hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, b.facc, npix, color);
+    hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, facc, b.npix, color);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    if ((e = hipEventRecord(b.facc_done[fset], stream)) != hipSuccess) return (int)e;
+    b.facc_used[fset] = true;
   }
   return 0;
 }

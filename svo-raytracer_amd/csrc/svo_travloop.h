@@ -312,7 +312,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       : [px] "+v"(r.px), "+{v[68:69]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v72}"(r.sexp), [h] "+v"(r.h),
         [scale] "+v"(r.scale), [idx] "+v"(r.idx), [pbase] "+v"(r.pbase), [pmask] "+v"(r.pmask), [wr] "+v"(r.written),
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [cptr] "+v"(r.cptr), [tag] "+v"(r.tag),
-        "={v88}"(r.rlo), "={v89}"(r.rhi), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        "=&{v88}"(r.rlo), "=&{v89}"(r.rhi), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
         [t3] "=&v"(t3), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd),
         [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh), [cnt] "=&s"(cnt)
       : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [cone] "v"(r.cone_t),

@@ -38,6 +38,8 @@ struct WfSet {
   float *state = nullptr;               // kStatePlanes planes of npix floats
   uint32_t *counters = nullptr;         // per stage: 8 heads + 8 counts, kWfStride apart
   float *facc = nullptr;                // spp > 1 colour sums
+  hipEvent_t done = nullptr;            // recorded behind the set's last kernel; the frame that re-uses the set waits for it
+  bool used = false;
 };
 struct WavefrontBuffers {
   WfSet set[kWfSets];
@@ -56,6 +58,7 @@ inline void wavefront_free(WavefrontBuffers &b) {
     if (s.state) (void)hipFree(s.state);
     if (s.counters) (void)hipFree(s.counters);
     if (s.facc) (void)hipFree(s.facc);
+    if (s.done) (void)hipEventDestroy(s.done);
     s = WfSet();
   }
   b.npix = 0; b.slots = 0;
@@ -385,8 +388,9 @@ inline int wavefront_prepare(WavefrontBuffers &b, const Frame &f, size_t out_npi
   const size_t tiles_per_band = (size_t)(f.ntiles + 7) / 8;
   const size_t slots = tiles_per_band * 8 * 64;
   if (b.npix < npix || b.slots < slots || !b.set[0].state) {
-    wavefront_free(b);
     hipError_t e;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;   // frames in flight may still use the old buffers
+    wavefront_free(b);
     for (auto &s : b.set) {
       if ((e = hipMalloc((void **)&s.rays[0], slots * 32)) != hipSuccess) return (int)e;
       if ((e = hipMalloc((void **)&s.rays[1], slots * 32)) != hipSuccess) return (int)e;
@@ -394,6 +398,7 @@ inline int wavefront_prepare(WavefrontBuffers &b, const Frame &f, size_t out_npi
       if ((e = hipMalloc((void **)&s.state, npix * kStatePlanes * sizeof(float))) != hipSuccess) return (int)e;
       if ((e = hipMalloc((void **)&s.counters, (size_t)(kWfMaxStages + 1) * 16 * kWfStride * 4)) != hipSuccess) return (int)e;
       if ((e = hipMalloc((void **)&s.facc, npix * 3 * sizeof(float))) != hipSuccess) return (int)e;
+      if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return (int)e;
     }
     b.npix = npix; b.slots = slots;
     int dev = 0, cus = 256, per_cu = 0;
@@ -430,6 +435,7 @@ inline int wavefront_launch(WavefrontBuffers &b, const uint8_t *pool, const Fram
   const int tiles_per_band = (f.ntiles + 7) / 8;
   const unsigned slot_blocks = (unsigned)(((size_t)tiles_per_band * 8 * 64 + 255) / 256);
   hipError_t e;
+  if (S.used && (e = hipStreamWaitEvent(stream, S.done, 0)) != hipSuccess) return (int)e;
   for (int s = 0; s < spp; s++) {
     if ((e = hipMemsetAsync(S.counters, 0, (size_t)(kWfMaxStages + 1) * 16 * kWfStride * 4, stream)) != hipSuccess)
       return (int)e;
@@ -465,6 +471,8 @@ inline int wavefront_launch(WavefrontBuffers &b, const uint8_t *pool, const Fram
     hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, stream, f, S.facc, b.npix, color);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   }
+  if ((e = hipEventRecord(S.done, stream)) != hipSuccess) return (int)e;
+  S.used = true;
   return 0;
 }
 

@@ -16,7 +16,7 @@ EXPORTS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
     "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
-    "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits",
+    "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel",
     "svo_output_device_ptrs",
 ]
 
@@ -76,6 +76,7 @@ def lib(path=None):
         L.svo_read_color.argtypes = [vp, vp]
         L.svo_read_depth.argtypes = [vp, vp]
         L.svo_read_hits.argtypes = [vp, vp]
+        L.svo_read_pixel.argtypes = [vp, ci, ci, vp, vp, vp]
         L.svo_output_device_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
         for n in EXPORTS:
             if n != "svo_last_error":
@@ -219,6 +220,13 @@ class HipContext:
         out = np.zeros((self.height, self.width), dtype=HIT_DTYPE)
         self._chk(self._L.svo_read_hits(self._h, out.ctypes.data))
         return out
+
+    def read_pixel(self, x, y):
+        rgba = np.zeros(4, dtype=np.uint8)
+        depth = np.zeros(1, dtype=np.float32)
+        hit = np.zeros(1, dtype=HIT_DTYPE)
+        self._chk(self._L.svo_read_pixel(self._h, int(x), int(y), rgba.ctypes.data, depth.ctypes.data, hit.ctypes.data))
+        return rgba, float(depth[0]), hit[0]
 
     def output_device_ptrs(self):
         a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
