@@ -2,64 +2,144 @@
 """bench.py -- the reference's headline metric on MI355X.
 
 Metric (BASELINE.json): Mrays/s (primary + 1 bounce) at 1920x1080 on an 8192^3 SVO.
-A "step" is one frame: every pixel's primary ray + its diffuse bounce (renderMode 0, the
-reference's GI mode, svotrace.comp:443-560) through the HIP path, pool resident in HBM.
-Rays = intersectOctree-equivalent casts actually performed (counted by an untimed
-counting pass of the same frame); value = rays of all ranks / wall time of K steps.
+A "step" is one frame of the reference's loop (Main.updateEarly, Main.java:257-289): frameNumber is
+pre-incremented every frame (first frame = 2), so every timed frame is a different frame (its bounce
+directions change, svotrace.comp:486); every pixel's primary ray + its diffuse bounce (renderMode 0,
+the reference's GI mode, svotrace.comp:443-560) go through the HIP path, pool resident in HBM.
+Rays = intersectOctree-equivalent casts actually performed (untimed counting pass of the first and
+the last timed frame); value = rays of all ranks / wall time of K steps.
 
-N > 1 (one process per GPU, launched by torch.distributed.run).  The path shards by
-screen tile: the pool is replicated by one RCCL broadcast, every rank renders every
-N-th 8-pixel tile row (interleaved stripes, packed into one band of the gather buffer), and each step's bands are gathered to rank 0 over xGMI (RCCL
-gather = one direct send per peer), overlapped with the next frame's traversal on a
-second stream.  Default --scaling weak: the per-GPU band stays 1920x1080 and the frame
-grows to 1920 x (1080*N) rows (same camera, denser rows), so per-GPU work is fixed.
---scaling strong splits the SAME 1920x1080 frame into N bands instead; a 1.5 ms frame is
-then bounded by the longest single path (about 0.5 ms of dependent loads), see DESIGN.md.
+After the timed region the frames still held by the ring (the last `inflight` timed frames, as
+rendered with that many launches in flight) are read back and a pixel subsample of each is compared
+bit-for-bit with the CPU oracle: the line carries "verified": true, or the run exits non-zero.
 
-Also on the JSON line: roofline (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM)
-and cpu_baseline (the CPU oracle timed on a bounded pixel subsample of the same frame).
+N > 1: `python bench.py --gpus N` starts N ranks itself (a child torch.distributed.run, before this
+process touches the GPU); under torch.distributed.run it is one of the ranks.  The path shards by
+screen tile: the pool is replicated by one RCCL broadcast, every rank renders every N-th 8-pixel tile
+row of the SAME frame (--scaling strong, the default: SURVEY 8d "same frame, tile-split, wall time
+including the gather") packed into its chunk of the gather buffer, and each frame's chunks (colour +
+depth in one message) are gathered to rank 0 over xGMI (one direct send per peer), overlapped with
+the next frames' traversal.  --scaling weak keeps 1920x1080 pixels per GPU instead (the frame grows
+to 1920 x 1080*N rows of the same view).
+
+Presets: --config C2 | C3 (default, the metric) | C4 | C5 are BASELINE.json's configs.
+Also on the JSON line: roofline (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM, plus the
+instruction-issue figures that actually bind, from the committed PMC passes when they were taken on
+exactly these kernel sources) and cpu_baseline (the CPU oracle on a bounded subsample).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 1024            # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9
+VALU_CYCLES = 2.5       # measured: a SIMD retires one wave64 VALU instruction per ~2.5 cycles (profiles/r01b_calib_valu.txt)
+
+PRESETS = {
+    # name: size, width, height, mode, bounces (path segments), mirror mask, spp
+    "C2": dict(size=2048, width=1920, height=1080, mode=1, bounces=2, mirror=0, spp=1),
+    "C3": dict(size=8192, width=1920, height=1080, mode=0, bounces=2, mirror=0, spp=1),
+    "C4": dict(size=8192, width=3840, height=2160, mode=0, bounces=5, mirror=0b1000, spp=1),
+    "C5": dict(size=8192, width=1920, height=1080, mode=0, bounces=2, mirror=0, spp=64),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--size", type=int, default=8192, help="SVO resolution N (N^3 voxels)")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--mode", type=int, default=0, help="renderMode: 0 = GI primary + bounce (metric), 2 = primary + shadow")
-    ap.add_argument("--bounces", type=int, default=2, help="path segments in mode 0 (2 = primary + 1 bounce)")
+    ap.add_argument("--config", choices=sorted(PRESETS), default=None, help="BASELINE.json config preset (default: C3)")
+    ap.add_argument("--size", type=int, default=None, help="SVO resolution N (N^3 voxels)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--mode", type=int, default=None, help="renderMode: 0 = GI primary + bounce (metric), 2 = primary + shadow")
+    ap.add_argument("--bounces", type=int, default=None, help="path segments in mode 0 (2 = primary + 1 bounce)")
+    ap.add_argument("--mirror", type=lambda v: int(v, 0), default=None, help="bit mask of mirror materials (svotrace.comp:500-504)")
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel accumulated per frame (svotrace.comp:668-670)")
     ap.add_argument("--camera", default="K1")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SVO_BENCH_PIPELINE", "1")),
                     help="0 one thread per pixel, 1 persistent waves (default), 2 staged wavefront")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("SVO_BENCH_INFLIGHT", "3")),
                     help="frames in flight (streams x output buffers); the next frame fills the GPU while the "
                          "previous one drains its longest paths")
+    ap.add_argument("--waves", type=int, default=-1, help="persistent waves per CU and frame (-1 = 10 with frames in flight, else fill)")
+    ap.add_argument("--thresh", type=int, default=9, help="refill round threshold in sixteenths")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle sample time (0 = skip)")
     ap.add_argument("--hits", type=int, default=0, help="also store 16-byte hit records per pixel")
-    ap.add_argument("--deinterleave", type=int, default=0,
-                    help="rank 0 also reorders the gathered stripe-major tile buffers into frame order each step")
-    return ap.parse_args()
+    ap.add_argument("--verify", type=int, default=1, help="check the ring's frames against the CPU oracle after timing")
+    ap.add_argument("--beam", type=int, default=0, help="useBeamOptimization (coarse depth pre-pass, Main.java:257-266)")
+    ap.add_argument("--as-rank", default=None, help="r/n: render what rank r of n would, on one GPU, no communication")
+    args = ap.parse_args(argv)
+    preset = PRESETS[args.config or "C3"]
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start the N ranks as a child torch.distributed.run.  Nothing in this
+    process has touched the GPU yet (device_count() does not initialise it)."""
+    import torch
+    have = torch.cuda.device_count()
+    if args.gpus > have:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def source_hash():
+    """Hash of the kernel sources: PMC figures taken on other sources are not reported."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "svo-raytracer_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".h", ".hip", ".cpp")) or n == "Makefile":
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_for(key):
+    """Per-launch PMC means (profiles/pmc_per_launch.json, written by tools/pmc_pass.py on the GPU box from separate
+    rocprofv3 --pmc passes of this very command) -- only if they were taken on the current kernel sources."""
+    p = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
+    try:
+        j = json.load(open(p))
+    except Exception:
+        return None
+    e = j.get(key)
+    if not e or e.get("src_hash") != source_hash():
+        return None
+    return e
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -77,7 +157,7 @@ def main():
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
     from svo_raytracer_amd.cameras import CAMERAS
-    from svo_raytracer_amd.tiles import stripe_layout, gather_bands_to_root, deinterleave
+    from svo_raytracer_amd.framering import FrameRing, replicate_pool
 
     W, H = args.width, args.height
     cam = CAMERAS[args.camera]
@@ -90,13 +170,8 @@ def main():
         pool, sstats = scene.build_scene(args.size)
         nbytes = int(pool.size)
     if world > 1:
-        nb = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device="cuda")
-        dist.broadcast(nb, 0)
-        nbytes = int(nb.item())
-        dpool = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            dpool.copy_(torch.from_numpy(pool))
-        dist.broadcast(dpool, 0)
+        dpool = replicate_pool(dist, pool, rank, world)
+        nbytes = int(dpool.numel())
         torch.cuda.synchronize()
         ctx.pool_upload_device(dpool.data_ptr(), nbytes)
         del dpool
@@ -105,97 +180,53 @@ def main():
         ctx.pool_upload(pool)
     t_build = time.time() - t_build
 
-    # ---- frame state -----------------------------------------------------------------------
+    # ---- frame state -----------------------------------------------------------------------------
     H_total = H * world if args.scaling == "weak" else H
+    as_rank = tuple(int(v) for v in args.as_rank.split("/")) if args.as_rank else None
     ctx.resize(W, H_total)
     ctx.set_camera(cam)
-    ctx.set_params(2, args.mode, nbytes, 0, args.bounces, 0, 1)  # frameNumber 2 = first frame (Main.java:16,275)
     ctx.set_pipeline(args.pipeline)
-    if args.pipeline == 1 and max(2 if use_comm else 1, args.inflight) > 1:
-        ctx.set_tuning(10, 9)  # several frames in flight share the CUs: 10 persistent waves per CU and frame,
-                               # rounds once 7/16 of the traversing lanes have stopped (swept on MI355X, tools/sweep*.sh)
-    # rank r renders tile rows r, r + N, r + 2N, ... (interleaved: every rank sees the same mix of near and
-    # far terrain) and stores them packed in its band of the gather buffer
-    s_first, s_step, s_n, s_out0, rows_per_rank = stripe_layout(H_total, world, rank)
-    hp = rows_per_rank * world  # padded height so that every rank's band has the same size
-    nbuf = min(4, max(2 if use_comm else 1, args.inflight))  # frame k drains / is gathered while frame k+1 is traced
-    # (the library keeps a ring of 4+ per-frame work-counter / queue sets, so at most 4 frames may be in flight)
-    color = [torch.zeros((hp, W), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
-    depth = [torch.zeros((hp, W), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-    hits = [torch.zeros((hp, W, 4), dtype=torch.int32, device="cuda") for _ in range(nbuf)] if args.hits else None
-    scratch_c = torch.zeros((rows_per_rank, W), dtype=torch.int32, device="cuda") if use_comm and rank == 0 else None
-    scratch_d = torch.zeros((rows_per_rank, W), dtype=torch.float32, device="cuda") if use_comm and rank == 0 else None
+    nbuf = min(8, max(2 if use_comm else 1, args.inflight))
+    waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
+    if args.pipeline == 1:
+        ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and
+                                            # frame, rounds once 7/16 of the traversing lanes have stopped (tools/sweep*.sh)
     ctx.set_hit_records(bool(args.hits))
-    ctx.set_stripes(s_first, s_step, s_n, s_out0)
-    main_stream = torch.cuda.current_stream()
-    streams = [main_stream] + [torch.cuda.Stream() for _ in range(nbuf - 1)]
-    for st_ in streams[1:]:
-        st_.wait_stream(main_stream)
-    stream = main_stream
-    ctx.set_stream(stream.cuda_stream)
-    comm_stream = torch.cuda.Stream() if use_comm else None
-    gathered = [None] * nbuf  # event: the gather that last read buffer b has finished
-    state = {"k": 0, "timing": False}
-    launch_events = []        # (start, end) HIP events around every launch of the timed region, on its own stream
+    params = dict(render_mode=args.mode, buffer_end=nbytes, use_beam=args.beam, bounces=args.bounces,
+                  mirror_mask=args.mirror, spp=args.spp)
+    ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device="cuda",
+                     dist=dist if use_comm else None, want_hits=bool(args.hits), force_comm=force_comm,
+                     first_frame=2, params=params, as_rank=as_rank)
 
-    def step():
-        b = state["k"] % nbuf
-        state["k"] += 1
-        stream = streams[b]
-        ctx.set_stream(stream.cuda_stream)
-        if gathered[b] is not None:
-            stream.wait_event(gathered[b])
-        ctx.bind_outputs(color[b].data_ptr(), depth[b].data_ptr(), hits[b].data_ptr() if hits is not None else None)
-        if state["timing"]:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            ctx.dispatch_async()
-            e1.record(stream)
-            launch_events.append((e0, e1))
-        else:
-            ctx.dispatch_async()
-        if use_comm:
-            done = torch.cuda.Event()
-            done.record(stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(done)
-                gather_bands_to_root(dist, color[b], rank, world, rows_per_rank, force=force_comm, scratch=scratch_c)
-                gather_bands_to_root(dist, depth[b], rank, world, rows_per_rank, force=force_comm, scratch=scratch_d)
-                if rank == 0 and args.deinterleave:  # stripe-major as gathered -> frame order, on the frame owner
-                    frame_c = deinterleave(color[b], world, rows_per_rank, H_total)
-                    frame_d = deinterleave(depth[b], world, rows_per_rank, H_total)
-                    state["frame"] = (frame_c, frame_d)
-                ev = torch.cuda.Event()
-                ev.record(comm_stream)
-                gathered[b] = ev
+    # ---- ray count (untimed counting pass of the first and the last timed frame) ---------------------
+    def count(frame):
+        c, d, h = ring._ptrs(0)
+        ctx.set_stream(ring.streams[0].cuda_stream)
+        ctx.bind_outputs(c, d, h)
+        ctx.set_params(frame, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
+        return ctx.count_frame()
 
-    ctx.bind_outputs(color[0].data_ptr(), depth[0].data_ptr(), hits[0].data_ptr() if hits is not None else None)
-
-    def drain():
-        torch.cuda.synchronize()
-        ctx.set_stream(main_stream.cuda_stream)
-        ctx.bind_outputs(color[0].data_ptr(), depth[0].data_ptr(), hits[0].data_ptr() if hits is not None else None)
-
-    # ---- ray count of the frame (untimed counting pass; identical image) -------------------
-    cstats = ctx.count_frame()
-    counts = torch.tensor([cstats["rays"], cstats["iterations"], cstats["alg_bytes"], cstats["pixels"],
-                           cstats["nan_rays"]], dtype=torch.int64, device="cuda")
+    first_timed = 2 + args.warmup
+    last_timed = first_timed + args.steps - 1
+    ca, cb = count(first_timed), count(last_timed)
+    keys = ("rays", "iterations", "alg_bytes", "pixels", "nan_rays")
+    mine = [(ca[k] + cb[k]) / 2.0 for k in keys]
+    counts = torch.tensor(mine, dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(counts)
-    rays, iters, alg_bytes, pixels, nan_rays = [int(v) for v in counts.tolist()]
+    rays, iters, alg_bytes, pixels, nan_rays = [float(v) for v in counts.tolist()]
 
     for _ in range(args.warmup):
-        step()
+        ring.step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    state["timing"] = True
+    ring.timing = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        ring.step()
     torch.cuda.synchronize()
-    state["timing"] = False
+    ring.timing = False
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -205,14 +236,49 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- kernel time by HIP events on the dispatch stream (rank 0's band), one frame at a time ---
-    kernel_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in launch_events]))  # with nbuf launches in flight
-    drain()
+    # ---- the frames the ring still holds: the last nbuf timed frames, rendered with nbuf launches in flight ----
+    ring.drain()
+    verified, vinfo = None, None
+    if args.verify and rank == 0:
+        from oracle import oracle   # the checker; never on the timed path
+        step = 16 if W * H_total <= 1920 * 1080 * 2 else 32
+        if args.spp > 8:
+            step *= 4
+        rows_ok = ring.rendered_rows_mask().numpy()
+        bad, npx, frames = 0, 0, []
+        for b in range(nbuf):
+            if ring.frame_of[b] is None or ring.frame_of[b] < first_timed:
+                continue
+            imgs = ring.frame_images(b)
+            fr = imgs[0]
+            col = imgs[1].cpu().numpy().view(np.uint8).reshape(H_total, W, 4)
+            dep = imgs[2].cpu().numpy()
+            ref = oracle.render(pool, W, H_total, cam, fr, args.mode, bounces=args.bounces, mirror_mask=args.mirror,
+                                spp=args.spp, xstep=step, ystep=step, want_hits=False)
+            ys = np.arange(0, H_total, step)
+            ys = ys[rows_ok[ys]]
+            sub = np.ix_(ys, np.arange(0, W, step))
+            bad += int((col[sub] != ref["rgba"][sub]).any(axis=2).sum())
+            bad += int((dep.view(np.uint32)[sub] != ref["depth"].view(np.uint32)[sub]).sum())
+            npx += int(ys.size * len(range(0, W, step)))
+            frames.append(int(fr))
+        verified = bad == 0 and npx > 0
+        vinfo = "frames %s as left by the timed region (%d in flight), every %d-th pixel in x and y (%d pixels): " \
+                "rgba8 + depth bits vs the CPU oracle, %d mismatches" % (frames, nbuf, step, npx, bad)
+
+    # ---- kernel time by HIP events on the dispatch streams; then one frame at a time with the GPU to itself ----
+    kernel_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ring.launch_events]))  # with nbuf launches in flight
+    if args.pipeline == 1:
+        ctx.set_tuning(0, args.thresh)   # one frame at a time: fill the GPU
+    c0, d0, h0 = ring._ptrs(0)
+    ctx.bind_outputs(c0, d0, h0)
+    ctx.set_params(first_timed, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
     kms = ctx.time_frames(2, max(5, min(args.steps, 30)))
     kernel_ms_isolated = float(np.mean(kms))
     out_bytes_px = 8 + (16 if args.hits else 0)
-    my_alg = cstats["alg_bytes"] + cstats["pixels"] * out_bytes_px
+    my_alg = mine[2] + mine[3] * out_bytes_px
 
+    rc = 0
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays * args.steps / elapsed / 1e6
@@ -221,46 +287,58 @@ def main():
         # are the same number.
         achieved_per_launch = my_alg / (kernel_ms * 1e-3) / 1e9
         achieved = my_alg / (elapsed / args.steps) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "%d_%dx%d_m%d_p%d" % (args.size, W, H, args.mode, args.pipeline)
-                traffic = tj.get(key)
-            except Exception:
-                traffic = None
+        key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (args.size, W, H_total, args.mode, args.bounces, args.spp, args.pipeline, nbuf)
+        pmc = pmc_for(key) if world == 1 and as_rank is None else None
+        roof = {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": (int(pmc["fetch_size_kb"] * 1024 * 2 + pmc["write_size_kb"] * 1024) if pmc else None),
+            "kernel_ms": round(kernel_ms, 4), "launches_in_flight": nbuf,
+            "achieved_per_launch": round(achieved_per_launch, 2),
+            "kernel_ms_isolated": round(kernel_ms_isolated, 4), "alg_bytes_per_launch": int(my_alg),
+            "note": "kernel_ms > ms_per_step because %d launches overlap; achieved = bytes per launch / ms_per_step "
+                    "(device level), achieved_per_launch = bytes / kernel_ms; kernel_ms_isolated = one frame at a "
+                    "time, GPU filled by one launch" % nbuf,
+        }
+        if pmc:
+            # the roof that binds: instruction issue.  Wave-level VALU instructions per launch x 2.5 cycles over
+            # what 1024 SIMDs offer in one step; lane utilisation = thread-cycles / (64 x active VALU cycles)
+            roof["binding_roof"] = {
+                "kind": "valu-issue",
+                "valu_insts_per_launch": int(pmc["sq_insts_valu"]),
+                "valu_issue_frac": round(pmc["sq_insts_valu"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4),
+                "valu_lane_util": round(pmc["sq_thread_cycles_valu"] / (64.0 * pmc["sq_active_inst_valu"]), 4),
+                "src_hash": pmc["src_hash"], "from": "profiles/pmc_per_launch.json",
+            }
+        stripes = "%d GPU(s) x interleaved tile rows (%d pixel rows each), gathered to rank 0" % (world, ring.rows_per_rank)
+        if as_rank:
+            stripes = "what-if: the stripes of rank %d of %d on one GPU, no communication" % as_rank
         line = {
             "metric": "Mrays/s (primary + 1 bounce) at 1920x1080, 8192^3 SVO",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "verified": verified,
             "config": {
-                "workload": "%d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), camera %s, "
-                            "pipeline %d, %dx%d pixels of interleaved tile rows per GPU, %d GPU(s), gathered to rank 0" % (
-                                args.size, nbytes, W, H_total, args.mode,
-                                "primary + %d bounce" % (args.bounces - 1) if args.mode == 0 else "primary + shadow ray",
-                                args.camera, args.pipeline, W, rows_per_rank, world),
-                "rays_per_frame": rays, "iterations_per_ray": round(iters / max(rays, 1), 2),
-                "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": nan_rays,
-                "scene_build_s": round(t_build, 1), "frames_in_flight": nbuf,
+                "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %d spp, camera %s, "
+                            "frameNumber %d..%d (one per step), pipeline %d, %s" % (
+                                args.config or "C3", args.size, nbytes, W, H_total, args.mode,
+                                ("primary + %d bounce(s)%s" % (args.bounces - 1, ", mirror mask 0x%x" % args.mirror if args.mirror else ""))
+                                if args.mode == 0 else ("primary + shadow ray" if args.mode == 2 else "primary only"),
+                                args.spp, args.camera, first_timed, last_timed, args.pipeline, stripes),
+                "rays_per_frame": int(round(rays)), "iterations_per_ray": round(iters / max(rays, 1), 2),
+                "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": int(round(nan_rays)),
+                "scene_build_s": round(t_build, 1), "frames_in_flight": nbuf, "use_beam": args.beam,
+                "verification": vinfo,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel_ms": round(kernel_ms, 4), "launches_in_flight": nbuf,
-                "achieved_per_launch": round(achieved_per_launch, 2),
-                "kernel_ms_isolated": round(kernel_ms_isolated, 4), "alg_bytes_per_launch": int(my_alg),
-            },
+            "roofline": roof,
         }
-        # ---- CPU baseline: the oracle on a bounded subsample of the same frame, 1 thread ----
+        # ---- CPU baseline: the oracle on a bounded subsample of the same frames, 1 thread ----
         if args.cpu_seconds > 0 and world == 1:
             from oracle import oracle
-            probe = oracle.render(pool, W, H, cam, 2, args.mode, bounces=args.bounces, xstep=32, ystep=32,
-                                  want_hits=False)
+            okw = dict(bounces=args.bounces, mirror_mask=args.mirror, spp=args.spp, want_hits=False)
             t1 = time.perf_counter()
-            probe = oracle.render(pool, W, H, cam, 2, args.mode, bounces=args.bounces, xstep=32, ystep=32,
-                                  want_hits=False)
+            probe = oracle.render(pool, W, H, cam, 2, args.mode, xstep=64, ystep=64, **okw)
             dt = max(time.perf_counter() - t1, 1e-4)
             per_px = dt / max(probe["stats"]["pixels"], 1)
             want_px = args.cpu_seconds / per_px
@@ -268,25 +346,28 @@ def main():
             crays, cpix, nframes, dt = 0, 0, 0, 0.0
             t1 = time.perf_counter()
             while dt < args.cpu_seconds * 0.8 and nframes < 64:
-                smp = oracle.render(pool, W, H, cam, 2 + nframes, args.mode, bounces=args.bounces, xstep=stepxy,
-                                    ystep=stepxy, want_hits=False)
+                smp = oracle.render(pool, W, H, cam, 2 + nframes, args.mode, xstep=stepxy, ystep=stepxy, **okw)
                 crays += smp["stats"]["rays"]
                 cpix += smp["stats"]["pixels"]
                 nframes += 1
                 dt = time.perf_counter() - t1
             line["cpu_baseline"] = {
                 "value": round(crays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                "sample": "every %d-th pixel in x and y of the same frame, %d pass(es) with frameNumber 2.. "
+                "sample": "every %d-th pixel in x and y of the same frames, %d pass(es) with frameNumber 2.. "
                           "(%d pixels, %d rays, %.1f s), single-threaded C oracle; host has %d cores" % (
                               stepxy, nframes, cpix, crays, dt, os.cpu_count() or 0),
             }
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+        if args.verify and not verified:
+            print("bench.py: verification against the oracle FAILED: " + str(vinfo), file=sys.stderr)
+            rc = 1
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,199 @@
+"""Frame ring: the per-frame driving logic of bench.py, kept importable so that the N > 1 path
+(pool broadcast -> interleaved tile-row stripes -> gather to the frame owner -> de-interleave) runs
+unchanged under gloo on CPU tensors in tests/ and under RCCL on the GPUs.
+
+One step = one frame of the reference's loop (Main.updateEarly, Main.java:257-289): frameNumber is
+pre-incremented (first frame = 2), the uniforms are set, the frame is dispatched.  Here `nbuf` frames
+are in flight: frame k renders into buffer k % nbuf on stream k % nbuf, and -- with more than one
+rank -- its bands travel to rank 0 on a separate communication stream while frame k + 1 is traced.
+
+Gather buffer of one frame in flight, on every rank:  [world][planes][rows_per_rank][W] 32-bit words,
+planes = colour (rgba8), depth (f32 bits) [+ 4 words of hit record].  A rank renders its stripes PACKED
+into its own chunk (svo_set_stripes with out_row0 = 0, outputs bound at the chunk), so one contiguous
+chunk per rank and ONE gather per frame carry colour and depth together.
+
+The renderer is duck-typed (hiplib.HipContext on the GPU; tests pass a CPU stand-in):
+  set_stream(ptr) bind_outputs(color_ptr, depth_ptr, hits_ptr) set_params(...) dispatch_async()
+"""
+import torch
+
+from .tiles import TILE, stripe_layout
+
+
+class _NoStream:
+    """CPU stand-in for a torch.cuda stream / event (everything is synchronous there)."""
+    cuda_stream = 0
+
+    def wait_event(self, ev):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+    def record(self, s=None):
+        pass
+
+
+class FrameRing:
+    def __init__(self, renderer, width, height, world=1, rank=0, nbuf=3, device="cuda", dist=None,
+                 want_hits=False, force_comm=False, first_frame=2, params=None, as_rank=None):
+        """params: dict(render_mode, buffer_end, use_beam, bounces, mirror_mask, spp) -- constant over the run.
+        as_rank = (r, n): render what rank r of n would, without any communication (single-GPU what-if runs)."""
+        self.r = renderer
+        self.W, self.H = int(width), int(height)
+        self.world, self.rank = int(world), int(rank)
+        self.nbuf = int(nbuf)
+        self.dist = dist
+        self.cuda = torch.device(device).type == "cuda"
+        self.device = device
+        self.use_comm = dist is not None and (self.world > 1 or force_comm)
+        self.force_comm = force_comm
+        self.planes = 2 + (4 if want_hits else 0)
+        self.want_hits = want_hits
+        self.params = dict(render_mode=0, buffer_end=0, use_beam=0, bounces=2, mirror_mask=0, spp=1)
+        self.params.update(params or {})
+        self.k = 0
+        self.first_frame = int(first_frame)
+        lw, lr = (self.world, self.rank) if as_rank is None else (int(as_rank[1]), int(as_rank[0]))
+        self.layout_world = lw
+        self.s_first, self.s_step, self.s_n, _, self.rows_per_rank = stripe_layout(self.H, lw, lr)
+        self.chunk_world = self.world if as_rank is None else 1
+        rpr = self.rows_per_rank
+        # [world][planes][rpr][W] words; rank r's chunk is self.buf[b][r]
+        self.buf = [torch.zeros((self.chunk_world, self.planes, rpr, self.W), dtype=torch.int32, device=device)
+                    for _ in range(self.nbuf)]
+        self.frame_of = [None] * self.nbuf          # frameNumber held by each buffer
+        self.scratch = (torch.zeros((self.planes, rpr, self.W), dtype=torch.int32, device=device)
+                        if self.use_comm and self.rank == 0 else None)
+        if self.cuda:
+            main = torch.cuda.current_stream()
+            self.streams = [main] + [torch.cuda.Stream() for _ in range(self.nbuf - 1)]
+            for s in self.streams[1:]:
+                s.wait_stream(main)
+            self.comm_stream = torch.cuda.Stream() if self.use_comm else None
+        else:
+            self.streams = [_NoStream() for _ in range(self.nbuf)]
+            self.comm_stream = _NoStream() if self.use_comm else None
+        self.gathered = [None] * self.nbuf          # event: the gather that last read buffer b has finished
+        self.timing = False
+        self.launch_events = []
+        self.my_chunk = self.rank if as_rank is None else 0
+        if hasattr(self.r, "set_stripes"):
+            self.r.set_stripes(self.s_first, self.s_step, self.s_n, 0)
+
+    # ---- one frame ------------------------------------------------------------------------------
+    def _ptrs(self, b):
+        mine = self.buf[b][self.my_chunk]
+        word = 4
+        base = mine.data_ptr()
+        plane = self.rows_per_rank * self.W * word
+        return base, base + plane, (base + 2 * plane if self.want_hits else None)
+
+    def step(self):
+        b = self.k % self.nbuf
+        frame = self.first_frame + self.k
+        self.k += 1
+        stream = self.streams[b]
+        self.r.set_stream(stream.cuda_stream)
+        if self.gathered[b] is not None:
+            stream.wait_event(self.gathered[b])
+        c, d, h = self._ptrs(b)
+        self.r.bind_outputs(c, d, h)
+        p = self.params
+        self.r.set_params(frame, p["render_mode"], p["buffer_end"], p["use_beam"], p["bounces"], p["mirror_mask"], p["spp"])
+        self.frame_of[b] = frame
+        if self.timing and self.cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            self.r.dispatch_async()
+            e1.record(stream)
+            self.launch_events.append((e0, e1))
+        else:
+            self.r.dispatch_async()
+        if self.use_comm:
+            self._gather(b, stream)
+        return frame
+
+    def _gather(self, b, stream):
+        dist = self.dist
+        if self.cuda:
+            done = torch.cuda.Event()
+            done.record(stream)
+            ctxmgr = torch.cuda.stream(self.comm_stream)
+        else:
+            done = None
+            import contextlib
+            ctxmgr = contextlib.nullcontext()
+        with ctxmgr:
+            if done is not None:
+                self.comm_stream.wait_event(done)
+            full = self.buf[b]
+            mine = full[self.rank]
+            if self.rank == 0:
+                parts = [full[r] for r in range(self.world)]
+                parts[0] = self.scratch   # the owner's chunk is already in place; gather needs a slot for it
+                dist.gather(mine, gather_list=parts, dst=0)
+            else:
+                dist.gather(mine, gather_list=None, dst=0)
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(self.comm_stream)
+                self.gathered[b] = ev
+
+    # ---- after the run ----------------------------------------------------------------------------
+    def drain(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+            self.r.set_stream(self.streams[0].cuda_stream)
+
+    def frame_images(self, b):
+        """(frameNumber, colour [H][W] int32, depth [H][W] float32[, hits [H][W][4] int32]) of buffer b in frame
+        order, on the frame owner (rank 0) after drain(); with as_rank only the rows that rank rendered are valid."""
+        full = self.buf[b]                      # [chunks][planes][rpr][W]
+        per = self.rows_per_rank // TILE
+        cw = full.shape[0]
+        lw = self.layout_world
+
+        def order(x):                           # x: [chunks][rpr][W...] stripe-major -> frame order
+            if cw == lw:
+                v = x.reshape(cw, per, TILE, *x.shape[2:])
+                v = v.permute(1, 0, 2, *range(3, v.dim()))
+                return v.reshape(per * cw * TILE, *x.shape[2:])[: self.H]
+            # a single chunk of a wider layout (as_rank): scatter its tile rows to where they belong
+            out = torch.zeros((per * lw * TILE,) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+            v = out.reshape(per, lw, TILE, *x.shape[2:])
+            v[:, self.s_first] = x[0].reshape(per, TILE, *x.shape[2:])
+            return out[: self.H]
+
+        color = order(full[:, 0])
+        depth = order(full[:, 1]).view(torch.float32)
+        if self.want_hits:
+            # the hit image is pixel-major (16 bytes per pixel) inside the chunk's last four plane-sized slots
+            hits = order(full[:, 2:6].reshape(cw, self.rows_per_rank, self.W, 4))
+            return self.frame_of[b], color, depth, hits
+        return self.frame_of[b], color, depth
+
+    def rendered_rows_mask(self):
+        """bool [H]: rows this rank's stripes cover (all rows on the owner after a gather)."""
+        m = torch.zeros(self.H, dtype=torch.bool)
+        if self.use_comm or self.layout_world == 1:
+            m[:] = True
+            return m
+        for j in range(self.s_n):
+            y = (self.s_first + j * self.s_step) * TILE
+            m[y:y + TILE] = True
+        return m
+
+
+def replicate_pool(dist, pool_np, rank, world, device="cuda"):
+    """The pool is built once on rank 0 and replicated by one broadcast.  Returns a uint8 tensor on
+    `device` holding the pool on every rank."""
+    n = torch.tensor([int(pool_np.size) if rank == 0 else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, 0)
+    nbytes = int(n.item())
+    dpool = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if rank == 0:
+        dpool.copy_(torch.from_numpy(pool_np))
+    dist.broadcast(dpool, 0)
+    return dpool

@@ -1,0 +1,262 @@
+"""The configuration bench.py measures, under the oracle: pipeline 1, svo_set_tuning(10, 9), several persistent
+launches in flight on alternating streams, frameNumber advancing every frame -- plus the ordering the library
+guarantees for that usage (include/svo_hip.h): per-frame counter sets and sample accumulators are re-used only
+after the frame that used them has finished, and pool edits wait for every frame in flight."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from svo_raytracer_amd import hiplib
+    c = hiplib.HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def pool8192():
+    import svo_raytracer_amd.scene as scene
+    pool, st = scene.build_scene(8192)
+    return pool
+
+
+class Frames:
+    """n output sets (colour, depth, hits) as torch tensors + s streams; frame k -> set k, stream k % s."""
+
+    def __init__(self, ctx, w, h, n, s, rows=None):
+        import torch
+        self.torch = torch
+        self.ctx, self.w, self.h, self.n = ctx, w, h, n
+        rows = rows or h
+        self.col = [torch.zeros((rows, w), dtype=torch.int32, device="cuda") for _ in range(n)]
+        self.dep = [torch.zeros((rows, w), dtype=torch.float32, device="cuda") for _ in range(n)]
+        self.hit = [torch.zeros((rows, w, 4), dtype=torch.int32, device="cuda") for _ in range(n)]
+        self.streams = [torch.cuda.Stream() for _ in range(s)]
+        torch.cuda.synchronize()
+
+    def enqueue(self, k, frame, mode, bounces=2, mirror=0, spp=1):
+        st = self.streams[k % len(self.streams)]
+        self.ctx.set_stream(st.cuda_stream)
+        self.ctx.bind_outputs(self.col[k].data_ptr(), self.dep[k].data_ptr(), self.hit[k].data_ptr())
+        self.ctx.set_params(frame, mode, 0, 0, bounces, mirror, spp)
+        self.ctx.dispatch_async()
+
+    def done(self):
+        self.torch.cuda.synchronize()
+        self.ctx.set_stream(self.torch.cuda.current_stream().cuda_stream)
+        self.ctx.bind_outputs(None, None, None)
+
+    def get(self, k):
+        from svo_raytracer_amd import hiplib
+        h = self.hit[k].cpu().numpy().reshape(-1, 4).copy().view(hiplib.HIT_DTYPE).reshape(self.hit[k].shape[0], self.w)
+        return {"rgba": self.col[k].cpu().numpy().view(np.uint8).reshape(-1, self.w, 4), "depth": self.dep[k].cpu().numpy(),
+                "hits": h}
+
+
+def _eq(a, b):
+    return (np.array_equal(a["rgba"], b["rgba"]) and np.array_equal(a["depth"].view(np.uint32), b["depth"].view(np.uint32))
+            and a["hits"].tobytes() == b["hits"].tobytes())
+
+
+def test_bench_configuration_frames_in_flight_8192_1080p(ctx, pool8192):
+    """8192^3, 1920x1080, mode 0: 9 frames (frameNumber 2..10) enqueued back to back on 3 streams with the bench
+    tuning; every frame bit-equal to the same frame rendered alone, and to the oracle on a pixel subsample."""
+    from oracle import oracle
+    from svo_raytracer_amd.cameras import CAMERAS
+    w, h, cam = 1920, 1080, CAMERAS["K1"]
+    ctx.set_pipeline(1)
+    ctx.pool_upload(pool8192)
+    ctx.resize(w, h)
+    ctx.set_camera(cam)
+    ctx.set_tuning(10, 9)
+    fr = Frames(ctx, w, h, 9, 3)
+    try:
+        for k in range(9):
+            fr.enqueue(k, 2 + k, 0)
+        fr.done()
+        ctx.set_tuning(0, 0)
+        step = 24
+        sub = (slice(0, h, step), slice(0, w, step))
+        for k in range(9):
+            got = fr.get(k)
+            alone = ctx.render(None, None, None, None, 2 + k, 0)
+            assert _eq(got, alone), "frame %d in flight differs from the frame rendered alone" % (2 + k)
+            ref = oracle.render(pool8192, w, h, cam, 2 + k, 0, xstep=step, ystep=step)
+            assert (ref["rgba"][sub] == got["rgba"][sub]).all(), k
+            assert (ref["depth"].view(np.uint32)[sub] == got["depth"].view(np.uint32)[sub]).all(), k
+            for f in ("pointer", "value", "raw_normal", "level", "iter"):
+                assert (ref["hits"][f][sub] == got["hits"][f][sub]).all(), (k, f)
+        # consecutive frames really are different frames (bounce directions change with frameNumber)
+        assert not np.array_equal(fr.get(0)["rgba"], fr.get(1)["rgba"])
+    finally:
+        fr.done()
+        ctx.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_golden_case_with_frames_in_flight(ctx, pipeline):
+    """A reference-shader golden (llvmpipe) rendered while other frames of the same scene are in flight."""
+    from helpers import compare_with_golden, golden_case, golden_cases
+    name, poolkey = [c for c in golden_cases() if golden_case(*c)["mode"] == 0][0]
+    g = golden_case(name, poolkey)
+    ctx.set_pipeline(pipeline)
+    ctx.pool_upload(g["pool"])
+    ctx.resize(g["w"], g["h"])
+    ctx.set_camera(g["cam"])
+    ctx.set_tuning(10, 9)
+    fr = Frames(ctx, g["w"], g["h"], 9, 3)
+    try:
+        for k in range(9):
+            fr.enqueue(k, g["frame"] + (k % 3), g["mode"])
+        fr.done()
+        for k in range(0, 9, 3):
+            bad = compare_with_golden(fr.get(k), g)
+            assert bad == {key: 0 for key in bad}, (k, bad)
+        for k in range(3, 9):
+            assert _eq(fr.get(k), fr.get(k - 3))
+    finally:
+        fr.done()
+        ctx.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_more_frames_in_flight_than_the_library_ring_holds(ctx, pipeline):
+    """24 frames on 6 streams: the ring of per-frame counter sets (8) / queue sets (4) wraps several times while
+    earlier users are still running; the event the previous user recorded orders the re-use."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(1024)
+    w, h = 640, 360
+    ctx.set_pipeline(pipeline)
+    ctx.pool_upload(pool)
+    ctx.resize(w, h)
+    ctx.set_camera(CAMERAS["K1"])
+    ctx.set_tuning(3, 9)
+    fr = Frames(ctx, w, h, 24, 6)
+    try:
+        for k in range(24):
+            fr.enqueue(k, 2 + k % 4, (0, 2)[k % 2])
+        fr.done()
+        ctx.set_tuning(0, 0)
+        ref = {}
+        for k in range(24):
+            key = (2 + k % 4, (0, 2)[k % 2])
+            if key not in ref:
+                ref[key] = ctx.render(None, None, None, None, key[0], key[1])
+            assert _eq(fr.get(k), ref[key]), (k, key)
+    finally:
+        fr.done()
+        ctx.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_multi_sample_frames_in_flight_have_their_own_accumulators(ctx, pipeline):
+    """spp > 1 with frames in flight on alternating streams: one colour-sum buffer per frame in flight."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(512)
+    w, h = 480, 270
+    ctx.set_pipeline(pipeline)
+    ctx.pool_upload(pool)
+    ctx.resize(w, h)
+    ctx.set_camera(CAMERAS["K1"])
+    ctx.set_tuning(4, 9)
+    fr = Frames(ctx, w, h, 8, 4)
+    try:
+        for k in range(8):
+            fr.enqueue(k, 2 + k, 0, spp=3)
+        fr.done()
+        ctx.set_tuning(0, 0)
+        for k in range(8):
+            alone = ctx.render(None, None, None, None, 2 + k, 0, spp=3)
+            assert _eq(fr.get(k), alone), k
+    finally:
+        fr.done()
+        ctx.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_pool_edit_between_frames_in_flight_is_not_torn(ctx, pipeline):
+    """Frames A are in flight on three streams when the pool is edited (ranged svo_pool_update, then one that grows
+    and re-allocates the pool); frames B follow.  A == renders of the old pool, B == renders of the new one."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(1024)
+    w, h = 800, 450
+    ctx.set_pipeline(pipeline)
+    base = ctx.render(pool, w, h, CAMERAS["K1"], 2, 2)
+    ptrs = np.unique(base["hits"]["pointer"][base["hits"]["pointer"] != 0])
+    edited = pool.copy()
+    edited[ptrs[::2]] = 3                                    # recolour half of the visible voxels
+    grown = np.concatenate([edited, np.zeros(1 << 20, dtype=np.uint8)])   # + a tail: forces a re-allocation
+    lo, hi = int(ptrs.min()), int(ptrs.max()) + 1
+    ctx.set_tuning(6, 9)
+    fr = Frames(ctx, w, h, 9, 3)
+    try:
+        for k in range(3):
+            fr.enqueue(k, 2 + k, 2)
+        ctx.pool_update(edited, lo, hi)                      # waits for the three frames, then edits
+        for k in range(3, 6):
+            fr.enqueue(k, 2 + k - 3, 2)
+        ctx.pool_update(grown, pool.size, grown.size)        # grows the pool under three more frames in flight
+        for k in range(6, 9):
+            fr.enqueue(k, 2 + k - 6, 2)
+        fr.done()
+        ctx.set_tuning(0, 0)
+        old = [ctx.render(pool, w, h, CAMERAS["K1"], 2 + k, 2) for k in range(3)]
+        new = [ctx.render(edited, w, h, CAMERAS["K1"], 2 + k, 2) for k in range(3)]
+        assert not _eq(old[0], new[0])
+        for k in range(3):
+            assert _eq(fr.get(k), old[k]), ("before the edit", k)
+            assert _eq(fr.get(3 + k), new[k]), ("after the edit", k)
+            assert _eq(fr.get(6 + k), new[k]), ("after the growing edit", k)
+    finally:
+        fr.done()
+        ctx.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_packed_stripes_with_samples_beyond_the_frame_height(ctx, pipeline):
+    """H = 100, 3 ranks: rank 2's packed stripes occupy rows 80..111 of the gather buffer -- past H.  With spp > 1
+    the colour sums are indexed like the outputs, so they must be sized for the gather buffer, not for W x H."""
+    import torch
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    from svo_raytracer_amd.tiles import stripe_layout, deinterleave
+    pool, _ = scene.build_scene(256)
+    w, h, world = 200, 100, 3
+    ctx.set_pipeline(pipeline)
+    full = ctx.render(pool, w, h, CAMERAS["K1"], 2, 0, spp=3)
+    rpr = stripe_layout(h, world, 0)[4]
+    assert rpr * world > h
+    col = torch.zeros((rpr * world, w), dtype=torch.int32, device="cuda")
+    dep = torch.zeros((rpr * world, w), dtype=torch.float32, device="cuda")
+    ctx.bind_outputs(col.data_ptr(), dep.data_ptr(), None)
+    ctx.set_params(2, 0, 0, 0, 2, 0, 3)
+    try:
+        for r in range(world):
+            first, step, n, out0, rows = stripe_layout(h, world, r)
+            ctx.set_stripes(first, step, n, out0)
+            ctx.dispatch()
+        torch.cuda.synchronize()
+        got = deinterleave(col.cpu().numpy().view(np.uint8).reshape(rpr * world, w, 4), world, rpr, h)
+        gotd = deinterleave(dep.cpu().numpy(), world, rpr, h)
+        assert (got == full["rgba"]).all()
+        assert (gotd.view(np.uint32) == full["depth"].view(np.uint32)).all()
+        # the same stripes into the library's own W x H images do not fit: rejected, not written out of bounds
+        ctx.bind_outputs(None, None, None)
+        first, step, n, out0, rows = stripe_layout(h, world, 2)
+        ctx.set_stripes(first, step, n, out0)
+        with pytest.raises(hiplib.SvoError) as e:
+            ctx.dispatch()
+        assert e.value.code == -1
+        ctx.set_stripes(0, 1, 13, 0)      # the whole frame as stripes fits (last tile row partial)
+        ctx.dispatch()
+        assert (ctx.read_color() == full["rgba"]).all()
+    finally:
+        ctx.bind_outputs(None, None, None)
+        ctx.set_rows(0, h)
