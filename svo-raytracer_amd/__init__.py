@@ -7,3 +7,15 @@ Only what the hot path needs lives here:
   *.py     thin ctypes bindings used by tests/ and bench.py
 """
 __all__ = ["scene", "hiplib", "hostlib", "cameras", "tiles"]
+
+
+def one_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; libsvohip.so links the system ROCm by soname.
+    Two HIP runtimes in one process do not share the GPU (the second finds no device).  Loading torch's libraries
+    first makes the dynamic linker resolve libsvohip.so's dependency to the runtime that is already mapped, so a
+    Python process that uses both (bench.py, the tests: torch owns the gather buffers and RCCL) has exactly one.
+    Importing torch does not touch the GPU.  A process without torch (the Java host) simply uses the system ROCm."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass

@@ -44,6 +44,8 @@ def lib(path=None):
         if not os.path.exists(path):
             raise RuntimeError(f"HIP library missing: {path} (run __graft_entry__.build()); "
                                "the SVO hot path has no CPU fallback")
+        from . import one_hip_runtime
+        one_hip_runtime()
         L = ctypes.CDLL(path)
         vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
         fp = ctypes.POINTER(ctypes.c_float)

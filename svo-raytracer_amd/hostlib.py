@@ -15,6 +15,8 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} missing: run __graft_entry__.build()")
+        from . import one_hip_runtime
+        one_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.svoh_camera_new.restype = vp
