@@ -255,8 +255,7 @@ def main():
             dep = imgs[2].cpu().numpy()
             ref = oracle.render(pool, W, H_total, cam, fr, args.mode, bounces=args.bounces, mirror_mask=args.mirror,
                                 spp=args.spp, xstep=step, ystep=step, want_hits=False)
-            ys = np.arange(0, H_total, step)
-            ys = ys[rows_ok[ys]]
+            ys = np.flatnonzero(rows_ok)[::step]      # every step-th row of those this run rendered
             sub = np.ix_(ys, np.arange(0, W, step))
             bad += int((col[sub] != ref["rgba"][sub]).any(axis=2).sum())
             bad += int((dep.view(np.uint32)[sub] != ref["depth"].view(np.uint32)[sub]).sum())
