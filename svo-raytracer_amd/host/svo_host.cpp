@@ -33,28 +33,6 @@ int svoh_octree_get_child_pointer(void *o, int p) { return ((Octree *)o)->getChi
 void svoh_octree_set_leaf_mask(void *o, int p, int m) { ((Octree *)o)->setLeafMask(p, (uint16_t)m); }
 int svoh_octree_get_leaf_mask(void *o, int p) { return ((Octree *)o)->getLeafMask(p); }
 
-// OctreeThread.run (OctreeThread.java:20-23): createDummyHead + constructInnerOctree(size, 0, maxLOD, {0,0,0}, 0, voxels)
-void svoh_octree_construct(void *o, int size, int max_lod, const uint8_t *voxels, int chunk) {
-  Octree *oct = (Octree *)o;
-  oct->createDummyHead();
-  const int p[3] = {0, 0, 0};
-  oct->constructInnerOctree(size, 0, max_lod, p, 0, voxels, chunk);
-}
-
-// Octree.useSDFBrush with a Sphere / Box (Main.placeSDF, Main.java:338-353); cb = {start0, end0, start1, end1}
-void svoh_octree_brush_sphere(void *o, int ox, int oy, int oz, int radius, int value, int world_size, int max_lod, int *cb) {
-  const int org[3] = {ox, oy, oz};
-  Sphere s(org, radius);
-  Octree::ChangeBounds b = ((Octree *)o)->useSDFBrush(s, (uint8_t)value, world_size, max_lod);
-  cb[0] = b.start0; cb[1] = b.end0; cb[2] = b.start1; cb[3] = b.end1;
-}
-void svoh_octree_brush_box(void *o, int ox, int oy, int oz, int w, int h, int d, int value, int world_size, int max_lod, int *cb) {
-  const int org[3] = {ox, oy, oz};
-  Box s(org, w, h, d);
-  Octree::ChangeBounds b = ((Octree *)o)->useSDFBrush(s, (uint8_t)value, world_size, max_lod);
-  cb[0] = b.start0; cb[1] = b.end0; cb[2] = b.start1; cb[3] = b.end1;
-}
-
 // One frame the way the reference drives it: Main.preRun (:102-125) + Main.updateEarly (:267-285).
 // Returns 0 when the frame was rendered, 1 if the renderer reported an error.
 int svoh_render_frame(void *octree, void *camera, int width, int height, int frame_number, int render_mode,

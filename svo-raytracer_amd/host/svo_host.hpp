@@ -36,52 +36,6 @@ struct Constants {
 
 
 // ---------------------------------------------------------------------------------------------
-// sdf/SignedDistanceField.java, Sphere.java, Box.java -- integer SDFs of the edit brush.
-struct SignedDistanceField {
-  int origin[3] = {0, 0, 0}, min[3] = {0, 0, 0}, max[3] = {0, 0, 0};
-  virtual ~SignedDistanceField() {}
-  virtual int distance(const int pos[3]) const { (void)pos; return 0; }
-  // Util.packNormal(Util.normalize(diff))  (Util.java:140-159)
-  virtual uint16_t normal(const int pos[3], bool faceOutwards) const {
-    int d[3];
-    for (int i = 0; i < 3; i++) d[i] = faceOutwards ? pos[i] - origin[i] : origin[i] - pos[i];
-    const double len = std::sqrt(std::pow((double)d[0], 2) + std::pow((double)d[1], 2) + std::pow((double)d[2], 2));
-    int n[3];
-    for (int i = 0; i < 3; i++) n[i] = (int)(((double)d[i] / len) * 9) / 2 + 5;
-    return (uint16_t)(int16_t)(n[0] + n[1] * 10 + n[2] * 100);
-  }
-};
-struct Sphere : SignedDistanceField {   // sdf/Sphere.java
-  int radius;
-  Sphere(const int o[3], int r) : radius(r) {
-    for (int i = 0; i < 3; i++) { origin[i] = o[i]; min[i] = o[i] - r - 1; max[i] = o[i] + r + 1; }
-  }
-  int distance(const int pos[3]) const override {   // Util.getIntDistance(pos, origin) - radius
-    const double xsq = std::pow((double)(pos[0] - origin[0]), 2), ysq = std::pow((double)(pos[1] - origin[1]), 2),
-                 zsq = std::pow((double)(pos[2] - origin[2]), 2);
-    return (int)std::llround(std::sqrt(xsq + ysq + zsq)) - radius;   // Math.round(double) for non-negative values
-  }
-};
-struct Box : SignedDistanceField {      // sdf/Box.java
-  int width, height, depth;
-  Box(const int o[3], int w, int h, int d) : width(w), height(h), depth(d) {
-    const int hw = (int)std::ceil(w / 2.0f), hh = (int)std::ceil(h / 2.0f), hd = (int)std::ceil(d / 2.0f);
-    const int half[3] = {hw, hh, hd};
-    for (int i = 0; i < 3; i++) { origin[i] = o[i]; min[i] = o[i] - half[i]; max[i] = o[i] + half[i]; }
-  }
-  int distance(const int pos[3]) const override {   // Box.java:29-43 (the reference subtracts the full extents)
-    const int b[3] = {width, height, depth};
-    int q[3];
-    for (int i = 0; i < 3; i++) { q[i] = std::abs(pos[i] - origin[i]) - b[i]; if (q[i] < 0) q[i] = 0; }
-    int m = q[0] > q[1] ? q[0] : q[1];
-    m = m > q[2] ? m : q[2];
-    m = m < 0 ? m : 0;
-    const double l = std::sqrt(std::pow((double)(q[0] + m), 2) + std::pow((double)(q[1] + m), 2) + std::pow((double)(q[2] + m), 2));
-    return (int)l;
-  }
-};
-
-// ---------------------------------------------------------------------------------------------
 // Octree.java -- only what the hot path consumes: the byte pool and its node encoders.
 class Octree {
  public:
@@ -157,242 +111,6 @@ class Octree {
   }
 
 
-  // ---- builder from a dense voxel chunk (Octree.java:511-670) -------------------------------------
-  // voxelData is a CHUNK^3 byte grid indexed x | y << shift | z << 2*shift (the reference: 1024^3, shift 10,
-  // Octree.java:110-112).  constructInnerOctree(size, curLOD, maxLOD, pPos, parentPointer, voxelData) appends the
-  // 8 children of the node at parentPointer and recurses, exactly in the reference's order.
-  void constructInnerOctree(int size, int curLOD, int maxLOD, const int pPos[3], int parentPointer,
-                            const uint8_t *voxelData, int chunk = 1024) {
-    const int cSize = size / 2;
-    if (cSize == 0 || curLOD == maxLOD) return;
-    int shift = 0;
-    while ((1 << shift) < chunk) shift++;
-    auto vox = [&](int x, int y, int z) -> uint8_t { return voxelData[(size_t)x | ((size_t)y << shift) | ((size_t)z << (2 * shift))]; };
-    int children[8], cPos[8][3];
-    enum { INTERIOR, SURFACE_LEAF, NON_SURFACE_LEAF, SUBDIVIDABLE_LEAF } types[8];
-    for (int n = 0; n < 8; n++) {
-      cPos[n][0] = pPos[0] + (n & 1) * cSize; cPos[n][1] = pPos[1] + ((n >> 1) & 1) * cSize; cPos[n][2] = pPos[2] + ((n >> 2) & 1) * cSize;
-    }
-    if ((size_t)memOffset + 8 * NODE_SIZE > buffer.size()) buffer.resize(buffer.size() + buffer.size() / 2 + 4096, 0);
-    uint16_t leafMask = 0;
-    for (int n = 0; n < 8; n++) {
-      uint8_t first = vox(cPos[n][0], cPos[n][1], cPos[n][2]), value = first;
-      bool leaf = true;
-      if (curLOD + 1 != maxLOD) {   // :533-555
-        for (int i = cPos[n][2]; i < cPos[n][2] + cSize && leaf; i++)
-          for (int j = cPos[n][1]; j < cPos[n][1] + cSize && leaf; j++)
-            for (int k = cPos[n][0]; k < cPos[n][0] + cSize; k++) {
-              const uint8_t sample = vox(k, j, i);
-              if (sample != 0) value = sample;
-              if (sample != first) {
-                if (first == 0) first = sample;
-                value = first;
-                leaf = false;
-                break;
-              }
-            }
-      }
-      if (leaf && value != 0) {
-        if (cSize == 1) {
-          // genSurfaceNormal (:620-649)
-          bool exposed = false;
-          int nx = 0, ny = 0, nz = 0;
-          for (int i = cPos[n][0] - 1; i <= cPos[n][0] + 1; i++) {
-            if (i < 0 || i >= chunk) continue;
-            for (int j = cPos[n][1] - 1; j <= cPos[n][1] + 1; j++) {
-              if (j < 0 || j >= chunk) continue;
-              for (int k = cPos[n][2] - 1; k <= cPos[n][2] + 1; k++) {
-                if (k < 0 || k >= chunk) continue;
-                if (vox(i, j, k) == 0) { exposed = true; nx += i - cPos[n][0]; ny += j - cPos[n][1]; nz += k - cPos[n][2]; }
-              }
-            }
-          }
-          if (exposed) {
-            children[n] = createSurfaceLeafNode(value, (uint16_t)((nx / 2 + 5) + (ny / 2 + 5) * 10 + (nz / 2 + 5) * 100));
-            types[n] = SURFACE_LEAF;
-          } else {
-            children[n] = createNonSurfaceLeafNode(value);
-            types[n] = NON_SURFACE_LEAF;
-          }
-        } else {
-          // checkBigNodeExposed (:651-670): only coordinates {c-1, c+cSize, c+cSize+1} per axis are examined
-          bool exposed = false;
-          for (int i = cPos[n][2] - 1; i <= cPos[n][2] + cSize + 1; i++) {
-            if (i < 0 || i >= chunk || (i >= cPos[n][2] && i <= cPos[n][2] + cSize - 1)) continue;
-            for (int j = cPos[n][1] - 1; j <= cPos[n][1] + cSize + 1; j++) {
-              if (j < 0 || j >= chunk || (j >= cPos[n][1] && j <= cPos[n][1] + cSize - 1)) continue;
-              for (int k = cPos[n][0] - 1; k <= cPos[n][0] + cSize + 1; k++) {
-                if (k < 0 || k >= chunk || (k >= cPos[n][0] && k <= cPos[n][0] + cSize - 1)) continue;
-                if (vox(k, j, i) == 0) exposed = true;
-              }
-            }
-          }
-          if (exposed) { children[n] = createInteriorNode(value); types[n] = INTERIOR; }
-          else { children[n] = createSubdividableLeafNode(value); types[n] = SUBDIVIDABLE_LEAF; }
-        }
-      } else if (leaf) {
-        if (cSize == 1) { children[n] = createNonSurfaceLeafNode(value); types[n] = NON_SURFACE_LEAF; }
-        else { children[n] = createSubdividableLeafNode(value); types[n] = SUBDIVIDABLE_LEAF; }
-      } else {
-        children[n] = createInteriorNode(value);
-        types[n] = INTERIOR;
-      }
-      switch (types[n]) {   // :589-599
-        case SURFACE_LEAF: leafMask = (uint16_t)(leafMask | (0x0001 << (n << 1))); break;
-        case SUBDIVIDABLE_LEAF: leafMask = (uint16_t)(leafMask | (0x0002 << (n << 1))); break;
-        case NON_SURFACE_LEAF: leafMask = (uint16_t)(leafMask | (0x0003 << (n << 1))); break;
-        case INTERIOR: break;
-      }
-      if ((size_t)memOffset + 8 * NODE_SIZE > buffer.size()) buffer.resize(buffer.size() + buffer.size() / 2 + 4096, 0);
-    }
-    setChildPointer(parentPointer, children[0]);
-    setLeafMask(parentPointer, leafMask);
-    for (int n = 0; n < 8; n++)
-      if (getValue(children[n]) != 0 && types[n] == INTERIOR)
-        constructInnerOctree(cSize, curLOD + 1, maxLOD, cPos[n], children[n], voxelData, chunk);
-  }
-
-  // ---- SDF brush edits (Octree.java:672-956): the producer of ranged pool updates ---------------
-  struct ChangeBounds {   // :676-688
-    int start0, end0, start1, end1;
-  };
-  static constexpr uint8_t DELETE_VALUE = 127;        // Constants.java:16
-  static constexpr int MARCH_DISTANCE_MIN_CUTOFF = 5; // Constants.java:32
-  // Octree.useSDFBrush(sdf, value) (:700-708).  The reference hard-codes the root size
-  // Constants.WORLD_SIZE = 8196 (sic) and maxLOD 13; both are parameters here so that small test worlds work.
-  ChangeBounds useSDFBrush(const SignedDistanceField &sdf, uint8_t value, int worldSize = Constants::WORLD_SIZE,
-                           int maxLOD = 13) {
-    ChangeBounds cb{memOffset, 0, memOffset, memOffset};
-    const int pos[3] = {0, 0, 0};
-    brush(sdf, 0, 0, 0, worldSize, pos, false, value, 0, maxLOD, cb);
-    return cb;
-  }
-  struct NodeInfo { int pointer; int pos[3]; int childNumber; bool isLeaf; };
-  // forEachChild (:901-923): children of `parent` with their positions and leaf flags
-  std::vector<NodeInfo> children(int parent, const int pPos[3], int pSize) const {
-    std::vector<NodeInfo> out;
-    int cp = getChildPointer(parent);
-    const uint16_t mask = getLeafMask(parent);
-    const int cs = pSize / 2;
-    for (int i = 0; i < 8; i++) {
-      const int tag = (mask >> (i << 1)) & 3;
-      NodeInfo ni;
-      ni.pointer = cp; ni.childNumber = i; ni.isLeaf = tag != 0;
-      ni.pos[0] = pPos[0] + (i & 1) * cs; ni.pos[1] = pPos[1] + ((i >> 1) & 1) * cs; ni.pos[2] = pPos[2] + ((i >> 2) & 1) * cs;
-      out.push_back(ni);
-      cp += tag == 1 ? LEAF_SIZE : (tag == 3 ? NON_SURFACE_LEAF_SIZE : NODE_SIZE);
-    }
-    return out;
-  }
-
- private:
-  static bool intersectAABB(const int a0[3], const int a1[3], const int b0[3], const int b1[3]) {  // Util.java:5-9
-    return a0[0] <= b1[0] && a1[0] >= b0[0] && a0[1] <= b1[1] && a1[1] >= b0[1] && a0[2] <= b1[2] && a1[2] >= b0[2];
-  }
-  void updateExistingNodeBounds(ChangeBounds &cb, int start0, int end0) {   // :690-698
-    if (cb.start0 > start0) cb.start0 = start0;
-    if (cb.end0 < end0 + NODE_SIZE && end0 < cb.start1) cb.end0 = end0 + NODE_SIZE;
-  }
-  // the private recursive useSDFBrush (:710-827)
-  void brush(const SignedDistanceField &sdf, int cur, int parent, int childNumber, int size, const int pos[3],
-             bool isLeaf, uint8_t value, int curLOD, int maxLOD, ChangeBounds &cb) {
-    const int nodeMax[3] = {pos[0] + size, pos[1] + size, pos[2] + size};
-    if (!intersectAABB(pos, nodeMax, sdf.min, sdf.max)) return;
-    int mn[3];
-    for (int i = 0; i < 3; i++) mn[i] = pos[i] > sdf.min[i] ? pos[i] : sdf.min[i];
-    bool containsVolume = false, bordersVolume = false, containsAir = false;
-    const int cSize = size / 2;
-    for (int i = mn[0]; i < pos[0] + size; i++) {
-      for (int j = mn[1]; j < pos[1] + size; j++) {
-        for (int k = mn[2]; k < pos[2] + size; k++) {
-          const int lp[3] = {i, j, k};
-          const int dist = sdf.distance(lp);
-          const int ad = dist < 0 ? -dist : dist;
-          if (dist <= 0) containsVolume = true;
-          if (dist == 1 || dist == 0) bordersVolume = true;
-          if (dist > 0) containsAir = true;
-          int march = ad - 2;
-          if (march < MARCH_DISTANCE_MIN_CUTOFF) march = 0;
-          k += march;
-          if (containsVolume && containsAir) break;
-        }
-        if (containsVolume && containsAir) break;
-      }
-      if (containsVolume && containsAir) break;
-    }
-    if (!containsVolume && !bordersVolume) return;
-    if (bordersVolume && size > 1 && isLeaf && value != 0) {
-      subdivideNode(parent, cur, value, childNumber, cSize, pos, curLOD, maxLOD, sdf, cb);
-    } else if (containsVolume) {
-      if (isLeaf) {
-        if (!containsAir) {
-          setValue(cur, value);
-          updateExistingNodeBounds(cb, cur, cur);
-        } else {
-          subdivideNode(parent, cur, value, childNumber, cSize, pos, curLOD, maxLOD, sdf, cb);
-        }
-        return;
-      } else {
-        if (!containsAir) {
-          setValue(cur, value);
-          uint16_t pm = getLeafMask(parent);
-          pm = (uint16_t)(pm & ~(0x0003 << (childNumber << 1)));
-          pm = (uint16_t)(pm | (0x0002 << (childNumber << 1)));
-          setLeafMask(parent, pm);
-          updateExistingNodeBounds(cb, parent, cur);
-          for (const NodeInfo &ni : children(cur, pos, size)) setValue(ni.pointer, DELETE_VALUE);  // markNodeAsDirty
-          return;
-        }
-        for (const NodeInfo &ni : children(cur, pos, size))
-          brush(sdf, ni.pointer, cur, ni.childNumber, cSize, ni.pos, ni.isLeaf, value, curLOD + 1, maxLOD, cb);
-      }
-    } else if (bordersVolume && size > 1) {
-      if (isLeaf) {
-        subdivideNode(parent, cur, value, childNumber, cSize, pos, curLOD, maxLOD, sdf, cb);
-      } else {
-        for (const NodeInfo &ni : children(cur, pos, size))
-          brush(sdf, ni.pointer, cur, ni.childNumber, cSize, ni.pos, ni.isLeaf, value, curLOD + 1, maxLOD, cb);
-      }
-    }
-  }
-  // subdivideNode (:829-885)
-  void subdivideNode(int parent, int cur, uint8_t value, int childNumber, int cSize, const int pos[3], int curLOD,
-                     int maxLOD, const SignedDistanceField &sdf, ChangeBounds &cb) {
-    const uint8_t currentValue = getValue(cur);
-    if (value == currentValue) return;
-    if (value != 0) {
-      setValue(cur, value);
-      updateExistingNodeBounds(cb, cur, cur);
-    }
-    uint16_t pm = getLeafMask(parent);
-    pm = (uint16_t)(pm & ~(0x0003 << (childNumber << 1)));
-    setLeafMask(parent, pm);
-    uint16_t curMask = 0;
-    updateExistingNodeBounds(cb, parent, cur);
-    if ((size_t)memOffset + 8 * NODE_SIZE > buffer.size()) buffer.resize(buffer.size() + buffer.size() / 2 + 4096, 0);
-    int ch[8], cPos[8][3];
-    for (int n = 0; n < 8; n++) {
-      cPos[n][0] = pos[0] + (n & 1) * cSize; cPos[n][1] = pos[1] + ((n >> 1) & 1) * cSize; cPos[n][2] = pos[2] + ((n >> 2) & 1) * cSize;
-    }
-    if (curLOD + 1 == maxLOD) {
-      for (int i = 0; i < 8; i++) {
-        curMask = (uint16_t)(curMask | (0x0001 << (i << 1)));
-        ch[i] = createSurfaceLeafNode(currentValue, sdf.normal(pos, value != 0));
-      }
-    } else {
-      for (int i = 0; i < 8; i++) {
-        curMask = (uint16_t)(curMask | (0x0002 << (i << 1)));
-        ch[i] = createSubdividableLeafNode(currentValue);
-      }
-    }
-    setLeafMask(cur, curMask);
-    setChildPointer(cur, ch[0]);
-    cb.end1 = memOffset;
-    for (int i = 0; i < 8; i++)
-      brush(sdf, ch[i], cur, i, cSize, cPos[i], true, value, curLOD + 1, maxLOD, cb);
-  }
-
- public:
   // adopt a pool produced elsewhere (procedural scene generator)
   void adopt(const uint8_t *pool, size_t n) {
     if (n > buffer.size()) buffer.resize(n);

@@ -43,9 +43,6 @@ def lib():
         L.svoh_octree_create_surface_leaf.argtypes = [vp, ci, ci]
         L.svoh_octree_set_child_pointer.argtypes = [vp, ci, ci]
         L.svoh_octree_set_leaf_mask.argtypes = [vp, ci, ci]
-        L.svoh_octree_construct.argtypes = [vp, ci, ci, vp, ci]
-        L.svoh_octree_brush_sphere.argtypes = [vp] + [ci] * 7 + [vp]
-        L.svoh_octree_brush_box.argtypes = [vp] + [ci] * 9 + [vp]
         L.svoh_render_frame.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
         _lib = L
     return _lib
@@ -152,25 +149,6 @@ class Octree:
 
     def getLeafMask(self, parent):
         return self._L.svoh_octree_get_leaf_mask(self._h, parent)
-
-    def constructInnerOctree(self, grid, maxLOD):
-        """OctreeThread.run: dummy head + constructInnerOctree over a dense grid[z, y, x] chunk (chunk = grid edge)"""
-        grid = np.ascontiguousarray(grid, dtype=np.uint8)
-        n = grid.shape[0]
-        self._L.svoh_octree_construct(self._h, n, int(maxLOD), grid.ctypes.data, n)
-
-    def useSDFBrushSphere(self, origin, radius, value, worldSize=8196, maxLOD=13):
-        """Octree.useSDFBrush(new Sphere(origin, radius), value) -> ChangeBounds (start0, end0, start1, end1)"""
-        cb = np.zeros(4, dtype=np.int32)
-        self._L.svoh_octree_brush_sphere(self._h, int(origin[0]), int(origin[1]), int(origin[2]), int(radius),
-                                         int(value), int(worldSize), int(maxLOD), cb.ctypes.data)
-        return [int(v) for v in cb]
-
-    def useSDFBrushBox(self, origin, w, h, d, value, worldSize=8196, maxLOD=13):
-        cb = np.zeros(4, dtype=np.int32)
-        self._L.svoh_octree_brush_box(self._h, int(origin[0]), int(origin[1]), int(origin[2]), int(w), int(h), int(d),
-                                      int(value), int(worldSize), int(maxLOD), cb.ctypes.data)
-        return [int(v) for v in cb]
 
 
 def render_frame(octree, camera, width, height, frame_number=2, render_mode=2):

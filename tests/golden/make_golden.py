@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import svo_raytracer_amd.scene as scene  # noqa: E402
 import poolbuilder  # noqa: E402
 from svo_raytracer_amd import hostlib  # noqa: E402
+from oracle import octree as restated  # noqa: E402
 
 SHADER = "/root/reference/src/shaders/svotrace.comp"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
@@ -58,15 +59,15 @@ KEDIT = rot_cam((1.5, 1.62, 1.55), -1.15, 0.4)     # looking down at the SDF-edi
 
 
 def edited_pool(base):
-    """A pool after SDF brush edits through the C++ mirror of Octree.useSDFBrush (Octree.java:700-885):
+    """A pool after SDF brush edits through the restatement of Octree.useSDFBrush (oracle/octree_restatement.cpp) (Octree.java:700-885):
     re-tagged interior nodes that keep stale child-pointer / mask bytes (quirk Q5), DELETE_VALUE (127)
     orphans, appended subtrees with SDF normals."""
     o = hostlib.Octree(4096)
     o.adopt(base)
-    o.useSDFBrushSphere((20, 24, 40), 7, 2, worldSize=64, maxLOD=6)      # add material 2
-    o.useSDFBrushSphere((44, 19, 24), 6, 0, worldSize=64, maxLOD=6)      # carve
-    o.useSDFBrushBox((34, 26, 30), 3, 5, 4, 3, worldSize=64, maxLOD=6)   # Main.java:246-248 style box
-    o.useSDFBrushSphere((30, 21, 30), 9, 1, worldSize=64, maxLOD=6)      # big fill: whole sub-trees become tag 2
+    restated.useSDFBrushSphere(o, (20, 24, 40), 7, 2, worldSize=64, maxLOD=6)      # add material 2
+    restated.useSDFBrushSphere(o, (44, 19, 24), 6, 0, worldSize=64, maxLOD=6)      # carve
+    restated.useSDFBrushBox(o, (34, 26, 30), 3, 5, 4, 3, worldSize=64, maxLOD=6)   # Main.java:246-248 style box
+    restated.useSDFBrushSphere(o, (30, 21, 30), 9, 1, worldSize=64, maxLOD=6)      # big fill: whole sub-trees become tag 2
     return o.getByteBuffer()
 
 

@@ -89,22 +89,6 @@ def test_svo_file_roundtrip(tmp_path):
     assert o2.memOffset == pool.size and (o2.getByteBuffer() == pool).all()
 
 
-@pytest.mark.parametrize("n", [16, 32, 64])
-def test_construct_inner_octree_matches_generator_and_brute_force(n):
-    """Octree.constructInnerOctree over a dense voxel chunk (Octree.java:511-670) gives the same
-    bytes as the procedural generator (which never materialises the grid) and as the numpy brute-force builder."""
-    import poolbuilder
-    grid = poolbuilder.terrain_grid(n)
-    o = hostlib.Octree(4096)
-    depth = int(np.log2(n))
-    o.constructInnerOctree(grid, depth)
-    got = o.getByteBuffer()
-    ref, _ = scene.build_scene(n)
-    assert got.size == ref.size and (got == ref).all()
-    brute, _ = poolbuilder.pool_from_grid(grid)
-    assert (got == brute).all()
-
-
 @pytest.mark.gpu
 def test_renderer_mirror_drives_one_frame_like_main():
     """Main.preRun + updateEarly through the C++ Renderer mirror == the oracle."""

@@ -1,9 +1,12 @@
-"""incremental pool updates from SDF brush edits
-(Octree.useSDFBrush / subdivideNode / ChangeBounds, Octree.java:672-885; Main.placeSDF, Main.java:338-353)."""
+"""incremental pool updates from SDF brush edits (Main.placeSDF, Main.java:338-353:
+Octree.useSDFBrush produces two byte ranges, Renderer.updateSSBO sends them).  The product side of that row is
+svo_pool_update; the edits themselves come from the oracle-side restatement of Octree.useSDFBrush /
+subdivideNode / ChangeBounds (oracle/octree_restatement.cpp, Octree.java:672-885; parity unpinned: no JDK)."""
 import numpy as np
 import pytest
 
 from svo_raytracer_amd import hostlib
+from oracle import octree as restated
 import svo_raytracer_amd.scene as scene
 from svo_raytracer_amd.cameras import CAMERAS, rot_cam
 
@@ -42,7 +45,7 @@ def test_brush_edits_stay_inside_change_bounds_and_keep_the_pool_valid():
     o.adopt(pool)
     for kind, org, r, val in EDITS:
         before = o.getByteBuffer()
-        cb = o.useSDFBrushSphere(org, r, val, worldSize=64, maxLOD=6)
+        cb = restated.useSDFBrushSphere(o, org, r, val, worldSize=64, maxLOD=6)
         after = o.getByteBuffer()
         n = before.size
         diff = np.nonzero(before != after[:n])[0]
@@ -63,7 +66,7 @@ def test_box_brush_matches_reference_distance_rule():
     o = hostlib.Octree(4096)
     pool, _ = scene.build_scene(64)
     o.adopt(pool)
-    cb = o.useSDFBrushBox((34, 30, 30), 3, 5, 4, 3, worldSize=64, maxLOD=6)
+    cb = restated.useSDFBrushBox(o, (34, 30, 30), 3, 5, 4, 3, worldSize=64, maxLOD=6)
     assert cb[3] > cb[2]
     assert scene.validate_pool(o.getByteBuffer())[0] == 0
 
@@ -83,7 +86,7 @@ def test_ranged_updates_render_like_a_full_upload(pipeline):
         ctx.set_pipeline(pipeline)
         ctx.pool_upload(pool)
         for kind, org, r, val in EDITS:
-            cb = o.useSDFBrushSphere(org, r, val, worldSize=64, maxLOD=6)
+            cb = restated.useSDFBrushSphere(o, org, r, val, worldSize=64, maxLOD=6)
             host = o.getByteBuffer()
             if cb[1] > cb[0]:
                 ctx.pool_update(host, cb[0], cb[1])
