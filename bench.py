@@ -163,22 +163,26 @@ def main():
     cam = CAMERAS[args.camera]
     ctx = hiplib.HipContext(local_rank)
 
-    # ---- scene: built once on rank 0, replicated by one RCCL broadcast -------------------
+    # ---- scene: built once on rank 0 (height / material maps on the host cores, the pool on the GPU by
+    # svo_build_from_heightmap), replicated by one RCCL broadcast ------------------------------------------
     t_build = time.time()
     pool = None
     if rank == 0:
-        pool, sstats = scene.build_scene(args.size)
-        nbytes = int(pool.size)
+        hmap, mmap = scene.scene_maps(args.size)
+        nbytes = ctx.build_from_heightmap(hmap, mmap)
+        t_build = time.time() - t_build
+        del hmap, mmap
+        pool = ctx.pool_download(nbytes)     # host copy: source of the broadcast, and what the oracle checks against
     if world > 1:
         dpool = replicate_pool(dist, pool, rank, world)
         nbytes = int(dpool.numel())
         torch.cuda.synchronize()
-        ctx.pool_upload_device(dpool.data_ptr(), nbytes)
+        if rank != 0:
+            ctx.pool_upload_device(dpool.data_ptr(), nbytes)
         del dpool
         torch.cuda.empty_cache()
-    else:
-        ctx.pool_upload(pool)
-    t_build = time.time() - t_build
+    if rank != 0:
+        t_build = time.time() - t_build
 
     # ---- frame state -----------------------------------------------------------------------------
     H_total = H * world if args.scaling == "weak" else H
@@ -327,7 +331,7 @@ def main():
                                 args.spp, args.camera, first_timed, last_timed, args.pipeline, stripes),
                 "rays_per_frame": int(round(rays)), "iterations_per_ray": round(iters / max(rays, 1), 2),
                 "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": int(round(nan_rays)),
-                "scene_build_s": round(t_build, 1), "frames_in_flight": nbuf, "use_beam": args.beam,
+                "scene_build_s": round(t_build, 2), "frames_in_flight": nbuf, "use_beam": args.beam,
                 "verification": vinfo,
             },
             "roofline": roof,

@@ -94,6 +94,18 @@ int svo_pool_reserve(svo_ctx *ctx, uint64_t nbytes);
 int svo_pool_upload_device(svo_ctx *ctx, const void *dptr, uint64_t nbytes);
 int svo_pool_device_ptr(svo_ctx *ctx, void **dptr, uint64_t *nbytes);
 
+/* ---- world generation -------------------------------------------------------------------- */
+/* replaces Octree.constructCompleteOctree(chunkGenShader, voxelTexture, heightmapTexture, materialTexture)
+ * (Octree.java:192-353): the chunkgen-heightmap.comp voxel rule (:16-28: a column is solid for y <= height, its top
+ * five layers take the material map's value, the rest value 1), OctreeThread / constructInnerOctree over 512^3
+ * sub-cubes of 1024^3 chunks (Octree.java:511-670, OctreeThread.java:20-23) and the chunk splice (:317-343) -- done on
+ * the GPU from the two maps, without the dense voxel grid.  height / material: host arrays of n*n elements indexed
+ * [z*n + x], heights already in voxels (the reference scales its 16-bit PNG sample by 2048/65536 in the shader),
+ * materials 1..255.  n = world edge, a power of two in 8..8192.  The result becomes the context's pool (as after
+ * svo_pool_upload; read it with svo_pool_download); *out_nbytes = its size.  SVO_E_TOOLARGE if it would not fit
+ * signed 32-bit child pointers. */
+int svo_build_from_heightmap(svo_ctx *ctx, const uint16_t *height, const uint8_t *material, int n, uint64_t *out_nbytes);
+
 /* ---- per-frame state (the shader's uniforms) ------------------------------------- */
 /* replaces glUniform3fv(8,pos), (1..4, l1,l2,r1,r2) (Main.java:269-273); values as
  * Camera.getUniform() returns them (Camera.java:142-151) */

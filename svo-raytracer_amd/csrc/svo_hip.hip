@@ -13,6 +13,7 @@
 #include "svo_fused.hip.h"
 #include "svo_persistent.hip.h"
 #include "svo_wavefront.hip.h"
+#include "svo_build.hip.h"
 
 using namespace svo;
 
@@ -210,6 +211,53 @@ int svo_pool_device_ptr(svo_ctx *c, void **dptr, uint64_t *nbytes) {
     return refresh_dword0(c);
   }
   return SVO_OK;
+}
+
+// ---------------------------------------------------------------- world generation
+__global__ void count_zero_bytes_kernel(const uint8_t *p, size_t n, unsigned int *zeros) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int z = 0;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) z += p[i] == 0 ? 1u : 0u;
+  if (z) atomicAdd(zeros, z);
+}
+
+int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *material, int n, uint64_t *out_nbytes) {
+  if (!c || !height || !material) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: null map");
+  if (n < 8 || n > 8192 || (n & (n - 1))) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: n must be a power of two in 8..8192");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  const size_t cells = (size_t)n * (size_t)n;
+  uint16_t *d_h = nullptr;
+  uint8_t *d_m = nullptr;
+  unsigned int *d_z = nullptr;
+  auto cleanup = [&]() { if (d_h) (void)hipFree(d_h); if (d_m) (void)hipFree(d_m); if (d_z) (void)hipFree(d_z); };
+  hipError_t e = hipMalloc((void **)&d_h, cells * 2);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_m, cells);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_z, 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_h, height, cells * 2, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_m, material, cells, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_z, 0, 4, c->stream);
+  unsigned int zeros = 0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(count_zero_bytes_kernel, dim3(1024), dim3(256), 0, c->stream, d_m, cells, d_z);
+    e = hipMemcpyAsync(&zeros, d_z, 4, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { cleanup(); return fail(c, SVO_E_HIP, std::string("svo_build_from_heightmap: ") + hipGetErrorString(e)); }
+  if (zeros) { cleanup(); return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: material 0 in the material map (0 is the empty voxel)"); }
+  build::Result r;
+  bool too_large = false;
+  e = build::build_pool(d_h, d_m, n, kPad, c->stream, r, &too_large);
+  cleanup();
+  if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_build_from_heightmap: ") + hipGetErrorString(e));
+  if (too_large) {
+    if (out_nbytes) *out_nbytes = r.len;
+    return fail(c, SVO_E_TOOLARGE, "pool must stay below 2^31 bytes");
+  }
+  if (c->d_pool) (void)hipFree(c->d_pool);
+  c->d_pool = r.pool; c->pool_len = r.len; c->pool_cap = r.cap;
+  if (out_nbytes) *out_nbytes = r.len;
+  return refresh_dword0(c);
 }
 
 // ---------------------------------------------------------------- frame state

@@ -14,7 +14,7 @@ HIT_DTYPE = np.dtype([("pointer", "<u4"), ("raw_normal", "<u2"), ("value", "u1")
 
 EXPORTS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
-    "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
+    "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel",
     "svo_output_device_ptrs",
@@ -58,6 +58,7 @@ def lib(path=None):
         L.svo_pool_download.argtypes = [vp, vp, u64]
         L.svo_pool_reserve.argtypes = [vp, u64]
         L.svo_pool_upload_device.argtypes = [vp, vp, u64]
+        L.svo_build_from_heightmap.argtypes = [vp, vp, vp, ci, ctypes.POINTER(u64)]
         L.svo_bind_outputs.argtypes = [vp, vp, vp, vp]
         L.svo_pool_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
         L.svo_set_camera.argtypes = [vp, fp, fp, fp, fp, fp]
@@ -135,6 +136,16 @@ class HipContext:
 
     def pool_upload_device(self, dptr, nbytes):
         self._chk(self._L.svo_pool_upload_device(self._h, ctypes.c_void_p(int(dptr)), int(nbytes)))
+
+    def build_from_heightmap(self, height, material):
+        """GPU world generation (svo_build_from_heightmap); returns the size of the new pool."""
+        height = np.ascontiguousarray(height, dtype=np.uint16)
+        material = np.ascontiguousarray(material, dtype=np.uint8)
+        n = height.shape[0]
+        assert height.shape == (n, n) and material.shape == (n, n)
+        nb = ctypes.c_uint64()
+        self._chk(self._L.svo_build_from_heightmap(self._h, height.ctypes.data, material.ctypes.data, n, ctypes.byref(nb)))
+        return int(nb.value)
 
     def bind_outputs(self, color_ptr, depth_ptr, hits_ptr=None):
         self._chk(self._L.svo_bind_outputs(self._h, ctypes.c_void_p(color_ptr or 0), ctypes.c_void_p(depth_ptr or 0),

@@ -39,6 +39,8 @@ def lib():
         L.svo_scene_free.restype = None
         L.svo_scene_height.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.svo_scene_height.restype = ctypes.c_int
+        L.svo_scene_maps.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.svo_scene_maps.restype = ctypes.c_int
         L.svo_pool_validate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SceneStats),
                                         ctypes.POINTER(ctypes.c_int)]
         L.svo_pool_validate.restype = ctypes.c_int
@@ -60,6 +62,17 @@ def build_scene(n, seed=1, amp=8):
     finally:
         L.svo_scene_free(p)
     return pool, st.as_dict()
+
+
+def scene_maps(n, seed=1, amp=8):
+    """The procedural terrain as (height u16 [n][n], material u8 [n][n]) indexed [z][x]: the inputs of the GPU
+    builder (hiplib.HipContext.build_from_heightmap), which yields the bytes build_scene() yields."""
+    h = np.zeros((n, n), dtype=np.uint16)
+    m = np.zeros((n, n), dtype=np.uint8)
+    rc = lib().svo_scene_maps(int(n), int(seed), int(amp), h.ctypes.data, m.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"svo_scene_maps({n}) failed rc={rc}")
+    return h, m
 
 
 def height(n, x, z, seed=1, amp=8):

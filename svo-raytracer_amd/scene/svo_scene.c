@@ -108,8 +108,24 @@ int svo_scene_height(int N, uint32_t seed, int amp_num, int x, int z) {
   return (int)h;
 }
 
-static inline uint8_t band_material(const scene_t *s, int x, int z) {
-  return (uint8_t)(2 + (mix32((uint32_t)(x >> 5) * 0x9E3779B1U ^ mix32((uint32_t)(z >> 5) + s->seed * 0x61C88647U)) & 1U));
+static inline uint8_t band_material_of(uint32_t seed, int x, int z) {
+  return (uint8_t)(2 + (mix32((uint32_t)(x >> 5) * 0x9E3779B1U ^ mix32((uint32_t)(z >> 5) + seed * 0x61C88647U)) & 1U));
+}
+static inline uint8_t band_material(const scene_t *s, int x, int z) { return band_material_of(s->seed, x, z); }
+
+/* The scene as the two maps the reference's world generator starts from (Octree.java:208-231: a height map and a
+   surface-material map; chunkgen-heightmap.comp:16-28 turns them into voxels): height[z*N + x] in voxels, the
+   column is solid for y <= height; material[z*N + x] = value of its top five layers.  Input of the GPU builder
+   (svo_build_from_heightmap), which must then produce the bytes svo_scene_build produces. */
+int svo_scene_maps(int N, uint32_t seed, int amp_num, uint16_t *height, uint8_t *material) {
+  if (N < 8 || N > 8192 || (N & (N - 1)) || !height || !material) return 1;
+#pragma omp parallel for schedule(static)
+  for (int z = 0; z < N; z++)
+    for (int x = 0; x < N; x++) {
+      height[(size_t)z * N + x] = (uint16_t)svo_scene_height(N, seed, amp_num, x, z);
+      material[(size_t)z * N + x] = band_material_of(seed, x, z);
+    }
+  return 0;
 }
 static inline int H(const scene_t *s, int x, int z) { return s->h[(size_t)z * s->N + x]; }
 /* voxel rule of chunkgen-heightmap.comp:16-28 */
