@@ -113,7 +113,12 @@ int svo_set_camera(svo_ctx *ctx, const float pos[3], const float l1[3], const fl
                    const float r2[3]);
 /* replaces glUniform1i(5 frameNumber | 6 renderMode | 9 bufferEnd | 11 useBeam)
  * (Main.java:275-283).  bounces / mirror_mask / spp expose the shader's dormant
- * features (svotrace.comp:444, 500-504, 668-670); the live behaviour is 2 / 0 / 1. */
+ * features (svotrace.comp:444, 500-504, 668-670); the live behaviour is 2 / 0 / 1.
+ * use_beam != 0 = useBeamOptimization (Main.java:51, 257-266, 280-283; default off): every dispatch is preceded by a
+ * coarse pass that finds, per 4x4 pixel block, a distance before which none of its rays can meet a voxel, and primary
+ * rays start their walk there.  The reference's own coarse pass (svobeam.comp) is dormant and inconsistent; here the
+ * feature is exact: colour, depth and the hit records' pointer / value / normal / level / t are the same bytes as with
+ * use_beam = 0, only the records' iteration counts drop (renderMode 1 displays them, so its colours change). */
 int svo_set_params(svo_ctx *ctx, int frame_number, int render_mode, int buffer_end, int use_beam, int bounces,
                    uint32_t mirror_mask, int spp);
 /* replaces the image allocations: rgba8 WxH on unit 0, r32f WxH on unit 1 (Main.java:66-78) */
@@ -163,6 +168,9 @@ int svo_time_frames(svo_ctx *ctx, int warmup, int iters, float *ms);
 int svo_read_color(svo_ctx *ctx, void *rgba8);
 int svo_read_depth(svo_ctx *ctx, float *depth);
 int svo_read_hits(svo_ctx *ctx, svo_hit *hits);
+/* the beam image of the last frame dispatched with use_beam (image unit 2 of the reference, Main.java:79-86):
+ * ceil(H/4) rows of ceil(W/4) floats; only the block rows under the rows that frame rendered are defined */
+int svo_read_beam(svo_ctx *ctx, float *beam);
 /* one pixel of the three images: what Main.updateEarly actually needs from its full-frame glGetTexImage
  * (Main.java:132-146 reads the 8.3 MB depth image to pick depth[540][960], the crosshair).  Any of
  * rgba8 (4 bytes) / depth / hit may be NULL.  Library-owned or bound outputs; waits for the context's stream. */

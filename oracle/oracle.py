@@ -47,6 +47,11 @@ def lib():
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.POINTER(Stats)]
         L.svo_oracle_render.restype = ctypes.c_int
+        L.svo_oracle_render_beam.argtypes = L.svo_oracle_render.argtypes + [ctypes.c_void_p]
+        L.svo_oracle_render_beam.restype = ctypes.c_int
+        L.svo_oracle_beam.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(Params), ctypes.c_void_p,
+                                      ctypes.POINTER(ctypes.c_uint64)]
+        L.svo_oracle_beam.restype = ctypes.c_int
         for name in ("sin", "cos", "acos", "exp2"):
             f = getattr(L, "svo_oracle_" + name)
             f.argtypes = [ctypes.c_float]
@@ -57,11 +62,7 @@ def lib():
     return _lib
 
 
-def render(pool, width, height, cam, frame_number=2, render_mode=2, bounces=2, mirror_mask=0, spp=1,
-           rows=None, xstep=1, ystep=1, want_hits=True):
-    """Run the CPU restatement. cam: 15 floats (pos,l1,l2,r1,r2). Returns dict with
-    rgba (H,W,4 u8), depth (H,W f32), hits (H,W HIT_DTYPE), stats."""
-    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+def _params(pool, width, height, cam, frame_number, render_mode, bounces, mirror_mask, spp):
     prm = Params()
     prm.width, prm.height = int(width), int(height)
     cam = np.asarray(cam, dtype=np.float32).reshape(15)
@@ -70,14 +71,41 @@ def render(pool, width, height, cam, frame_number=2, render_mode=2, bounces=2, m
     prm.frame_number, prm.render_mode = int(frame_number), int(render_mode)
     prm.buffer_end, prm.use_beam = int(pool.size), 0
     prm.bounces, prm.mirror_mask, prm.spp = int(bounces), int(mirror_mask), int(spp)
+    return prm
+
+
+BEAM_BLOCK = 4   # Main.java:41 beamSquareSize
+
+
+def beam(pool, width, height, cam, want_visits=False):
+    """The coarse pass of use_beam = 1: conservative start distance per 4x4 pixel block, float32 [ceil(H/4)][ceil(W/4)]."""
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    prm = _params(pool, width, height, cam, 2, 2, 2, 0, 1)
+    out = np.zeros(((height + BEAM_BLOCK - 1) // BEAM_BLOCK, (width + BEAM_BLOCK - 1) // BEAM_BLOCK), dtype=np.float32)
+    nv = ctypes.c_uint64()
+    rc = lib().svo_oracle_beam(pool.ctypes.data, pool.size, ctypes.byref(prm), out.ctypes.data, ctypes.byref(nv))
+    if rc != 0:
+        raise RuntimeError(f"svo_oracle_beam rc={rc}")
+    return (out, int(nv.value)) if want_visits else out
+
+
+def render(pool, width, height, cam, frame_number=2, render_mode=2, bounces=2, mirror_mask=0, spp=1,
+           rows=None, xstep=1, ystep=1, want_hits=True, use_beam=False):
+    """Run the CPU restatement. cam: 15 floats (pos,l1,l2,r1,r2). Returns dict with
+    rgba (H,W,4 u8), depth (H,W f32), hits (H,W HIT_DTYPE), stats.  use_beam: primary rays start at the coarse
+    pass's distance of their block (see svo_oracle_beam in svo_oracle.c); the result also carries "beam"."""
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    prm = _params(pool, width, height, cam, frame_number, render_mode, bounces, mirror_mask, spp)
+    tb = beam(pool, width, height, cam) if use_beam else None
     y0, y1 = (0, height) if rows is None else rows
     rgba = np.zeros((height, width, 4), dtype=np.uint8)
     depth = np.zeros((height, width), dtype=np.float32)
     hits = np.zeros((height, width), dtype=HIT_DTYPE) if want_hits else None
     st = Stats()
-    rc = lib().svo_oracle_render(pool.ctypes.data, pool.size, ctypes.byref(prm), int(y0), int(y1), int(xstep),
-                                 int(ystep), rgba.ctypes.data, depth.ctypes.data,
-                                 hits.ctypes.data if want_hits else None, ctypes.byref(st))
+    rc = lib().svo_oracle_render_beam(pool.ctypes.data, pool.size, ctypes.byref(prm), int(y0), int(y1), int(xstep),
+                                      int(ystep), rgba.ctypes.data, depth.ctypes.data,
+                                      hits.ctypes.data if want_hits else None, ctypes.byref(st),
+                                      tb.ctypes.data if tb is not None else None)
     if rc != 0:
         raise RuntimeError(f"svo_oracle_render rc={rc}")
-    return {"rgba": rgba, "depth": depth, "hits": hits, "stats": st.as_dict()}
+    return {"rgba": rgba, "depth": depth, "hits": hits, "stats": st.as_dict(), "beam": tb}

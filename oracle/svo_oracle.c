@@ -38,6 +38,7 @@
 #define MAX_SCALE 23
 #define MAX_DEPTH 13
 #define MAX_RAYCAST_ITERATIONS 1500u
+#define BEAM_BLOCK 4 /* Main.java:41 beamSquareSize */
 
 typedef struct svo_hit {
   uint32_t pointer;    /* byte offset of the hit node; 0 = miss */
@@ -251,7 +252,10 @@ typedef struct {
 static inline int all_nan3(vec3 v) { return isnan(v.x) && isnan(v.y) && isnan(v.z); }
 
 /* :211-432.  `invdir` of the reference is unused and omitted. */
-static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, int maxDepth, int coneTrace) {
+/* t_start: 0 everywhere in the reference.  With the beam pre-pass (use_beam, see svo_oracle_beam below) the primary
+   ray of a pixel starts its walk at the conservative distance of its 4x4 block: same origin, same coefficients,
+   only t_min is raised -- every later t is derived from cell corners, so the hit record keeps its bits. */
+static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, int maxDepth, int coneTrace, float t_start) {
   stackEntry octstack[MAX_SCALE + 1];
   memset(octstack, 0, sizeof octstack);
   res->debugColor = v3(0.3f, 0.3f, 0.6f);
@@ -280,6 +284,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
   float t_min = gmax(gmax(2.0f * tx_coef - tx_bias, 2.0f * ty_coef - ty_bias), 2.0f * tz_coef - tz_bias);
   float t_max = gmin(gmin(tx_coef - tx_bias, ty_coef - ty_bias), tz_coef - tz_bias);
   t_min = gmax(t_min, 0.0f);
+  t_min = gmax(t_min, t_start);
   float h = t_max;
 
   uint32_t idx = 0;
@@ -447,7 +452,7 @@ static void record_hit(svo_hit *hit, const castResult *res, int intersect) {
 }
 
 /* :435-646 */
-static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, vec3 origin, vec3 dir, float seed0,
+static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, float t_start, vec3 origin, vec3 dir, float seed0,
                   float seed1, float seed2, float *depth, svo_hit *hit) {
   castResult res;
   memset(&res, 0, sizeof res);
@@ -459,7 +464,7 @@ static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, vec3 o
   if (mode == 0) {
     for (int i = 0; i < prm->bounces; i++) {
       int coneTrace = i != 0;
-      intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, coneTrace);
+      intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, coneTrace, i == 0 ? t_start : 0.0f);
       if (i == 0) record_hit(hit, &res, intersect);
       if (!intersect && i == 0) {
         vec3 sky = v3(0.6725f, 0.8784f, 1.0f);
@@ -505,12 +510,12 @@ static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, vec3 o
     }
     return accum;
   } else if (mode == 1) {
-    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0);
+    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0, t_start);
     record_hit(hit, &res, intersect);
     *depth = intersect ? res.t : 0.0f;
     return res.debugColor;
   } else if (mode == 2) {
-    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0);
+    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0, t_start);
     record_hit(hit, &res, intersect);
     if (intersect) {
       *depth = res.t;
@@ -536,7 +541,7 @@ static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, vec3 o
       matcolor.z = lambdab * matcolor.z + (1.0f - lambdab) * 1.0f;
       /* shadow ray; `res` is reused exactly as in the reference (:607) */
       vec3 so = res.voxelPos;
-      int sh = intersect_octree(c, so, sun_dir, &res, MAX_DEPTH, 0);
+      int sh = intersect_octree(c, so, sun_dir, &res, MAX_DEPTH, 0, 0.0f);
       if (sh && res.t > res.scale * SQRT3_F) {
         matcolor = v3(matcolor.x - 0.2f, matcolor.y - 0.2f, matcolor.z - 0.2f);
       } else if (res.iter > 260) {
@@ -549,7 +554,7 @@ static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, vec3 o
       return v3(0.6725f - dir.y * 0.4f, 0.8784f - dir.y * 0.4f, 1.0f - dir.y * 0.25f);
     }
   } else if (mode == 3) {
-    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0);
+    intersect = intersect_octree(c, origin, dir, &res, MAX_DEPTH, 0, t_start);
     record_hit(hit, &res, intersect);
     if (intersect) {
       *depth = res.t;
@@ -577,8 +582,9 @@ static uint8_t unorm8(float x) {
  * GL images: rgba8 row-major, row 0 = p.y = 0 (svotrace.comp:662-664, 726-727).
  * Any of rgba / depth / hits may be NULL.
  */
-int svo_oracle_render(const uint8_t *pool, uint64_t pool_len, const svo_oracle_params *prm, int y0, int y1, int xstep,
-                      int ystep, uint8_t *rgba, float *depth_out, svo_hit *hits, svo_oracle_stats *stats) {
+int svo_oracle_render_beam(const uint8_t *pool, uint64_t pool_len, const svo_oracle_params *prm, int y0, int y1, int xstep,
+                           int ystep, uint8_t *rgba, float *depth_out, svo_hit *hits, svo_oracle_stats *stats,
+                           const float *beam) {
   svo_oracle_stats local;
   memset(&local, 0, sizeof local);
   ctx_t c = {pool, pool_len, stats ? stats : &local, 0};
@@ -608,7 +614,8 @@ int svo_oracle_render(const uint8_t *pool, uint64_t pool_len, const svo_oracle_p
       memset(&hit, 0, sizeof hit);
       for (int s = 0; s < spp; s++) {
         float d_s = 0.0f;
-        vec3 col = trace(&c, prm, 0.0f, camPos, normdir, (float)px, (float)py, (float)(prm->frame_number + s), &d_s,
+        const float t_start = beam ? beam[(size_t)(py / BEAM_BLOCK) * (size_t)((W + BEAM_BLOCK - 1) / BEAM_BLOCK) + (size_t)(px / BEAM_BLOCK)] : 0.0f;
+        vec3 col = trace(&c, prm, 0.0f, t_start, camPos, normdir, (float)px, (float)py, (float)(prm->frame_number + s), &d_s,
                          s == 0 ? &hit : NULL);
         if (s == 0) depth = d_s;
         fin = vadd(fin, col);
@@ -629,6 +636,137 @@ int svo_oracle_render(const uint8_t *pool, uint64_t pool_len, const svo_oracle_p
       c.st->pixels++;
     }
   }
+  return 0;
+}
+
+int svo_oracle_render(const uint8_t *pool, uint64_t pool_len, const svo_oracle_params *prm, int y0, int y1, int xstep,
+                      int ystep, uint8_t *rgba, float *depth_out, svo_hit *hits, svo_oracle_stats *stats) {
+  return svo_oracle_render_beam(pool, pool_len, prm, y0, y1, xstep, ystep, rgba, depth_out, hits, stats, NULL);
+}
+
+/* ------------------------------------------------------------------ beam pre-pass (use_beam)
+ *
+ * NOT a restatement of the reference: its beam pass (svobeam.comp:617-637, Main.java:257-266, svotrace.comp:438,
+ * 656-658) is dormant and inconsistent -- one full-depth ray through the corner pixel of every 4x4 block with an
+ * un-normalised direction, whose t then moves the origin of rays with normalised directions.  This is the CPU
+ * statement of the replacement the HIP library implements (csrc/svo_beam.hip.h), kept here as its checker:
+ *
+ *   for every 4x4 pixel block (beamSquareSize, Main.java:41) the pyramid of its rays -- the pixel footprints
+ *   widened by half a pixel -- is intersected with the octree itself: depth-first over the non-empty child
+ *   cubes that are not entirely outside one of the pyramid's four side planes, pruned by distance; a cube ends the
+ *   descent when it is a leaf, at MAX_DEPTH, or no larger than the pyramid is wide at its distance.  The block's
+ *   value is the smallest distance from the camera to such a cube, scaled by 1 - 2^-10: no ray of the block can
+ *   meet a non-empty voxel before it (rays have unit directions, so t is the distance travelled).
+ *
+ * Parity statement for use_beam = 1: hit pointer / value / normal / level / t and the colour and depth images equal
+ * those of use_beam = 0 (modes 0, 2, 3); iteration counts drop (mode 1 shows them, so its colours change).
+ */
+typedef struct {
+  uint32_t base;   /* offset of the first child record */
+  int mask;        /* child tags */
+  float x, y, z;   /* cube origin */
+  int next;        /* next child slot to look at */
+} beam_frame;
+
+static inline vec3 beam_dir(const svo_oracle_params *prm, float u, float v) {
+  const float *c = prm->cam;
+  vec3 a = v3(gmix(c[3], c[6], v), gmix(c[4], c[7], v), gmix(c[5], c[8], v));
+  vec3 b = v3(gmix(c[9], c[12], v), gmix(c[10], c[13], v), gmix(c[11], c[14], v));
+  return v3(gmix(a.x, b.x, u), gmix(a.y, b.y, u), gmix(a.z, b.z, u));
+}
+
+/* 1 if the camera is a finite planar image rectangle (r2 = r1 + l2 - l1 up to rounding): the pyramid of a block is
+   then bounded by the planes through its corner rays */
+static int beam_camera_ok(const svo_oracle_params *prm) {
+  const float *c = prm->cam;
+  for (int i = 0; i < 15; i++) if (!(fabsf(c[i]) < 1.0e30f)) return 0;
+  float ex = c[12] - (c[9] + (c[6] - c[3])), ey = c[13] - (c[10] + (c[7] - c[4])), ez = c[14] - (c[11] + (c[8] - c[5]));
+  float dx = c[12] - c[3], dy = c[13] - c[4], dz = c[14] - c[5];
+  float e2 = ex * ex + (ey * ey + ez * ez), d2 = dx * dx + (dy * dy + dz * dz);
+  return d2 > 0.0f && e2 <= 1.0e-8f * d2;
+}
+
+/* `visits` (may be NULL): number of child cubes looked at, summed over the blocks (diagnostic) */
+int svo_oracle_beam(const uint8_t *pool, uint64_t pool_len, const svo_oracle_params *prm, float *tbeam, uint64_t *visits) {
+  uint64_t nvisit = 0;
+  svo_oracle_stats dummy;
+  memset(&dummy, 0, sizeof dummy);
+  ctx_t c = {pool, pool_len, &dummy, 0};
+  if (pool_len < NODE_SIZE || prm->width <= 0 || prm->height <= 0) return 1;
+  const int W = prm->width, Hh = prm->height;
+  const int bw = (W + BEAM_BLOCK - 1) / BEAM_BLOCK, bh = (Hh + BEAM_BLOCK - 1) / BEAM_BLOCK;
+  const int cam_ok = beam_camera_ok(prm);
+  const vec3 o = v3(prm->cam[0], prm->cam[1], prm->cam[2]);
+  const Node root = extract_node(&c, 0);
+  for (int by = 0; by < bh; by++)
+    for (int bx = 0; bx < bw; bx++) {
+      float *out = &tbeam[(size_t)by * bw + bx];
+      *out = 0.0f;
+      if (!cam_ok) continue;
+      const float u0 = ((float)(bx * BEAM_BLOCK) - 0.5f) / (float)W, u1 = ((float)(bx * BEAM_BLOCK + BEAM_BLOCK) + 0.5f) / (float)W;
+      const float v0 = ((float)(by * BEAM_BLOCK) - 0.5f) / (float)Hh, v1 = ((float)(by * BEAM_BLOCK + BEAM_BLOCK) + 0.5f) / (float)Hh;
+      const vec3 d00 = beam_dir(prm, u0, v0), d10 = beam_dir(prm, u1, v0), d01 = beam_dir(prm, u0, v1), d11 = beam_dir(prm, u1, v1);
+      const vec3 dc = beam_dir(prm, 0.5f * (u0 + u1), 0.5f * (v0 + v1));
+      vec3 n[4] = {gcross(d00, d01), gcross(d11, d10), gcross(d10, d00), gcross(d01, d11)};
+      int planes_ok = 1;
+      for (int k = 0; k < 4; k++) {
+        const float s = dot3(n[k], dc);
+        if (s < 0.0f) n[k] = v3(-n[k].x, -n[k].y, -n[k].z);
+        else if (!(s > 0.0f)) planes_ok = 0;
+      }
+      if (!planes_ok) continue;
+      /* width of the pyramid per unit distance, squared (the wider of its two image-plane edges over the centre ray) */
+      const vec3 eu = v3(d10.x - d00.x, d10.y - d00.y, d10.z - d00.z), ev = v3(d01.x - d00.x, d01.y - d00.y, d01.z - d00.z);
+      const float spread2 = gmax(dot3(eu, eu), dot3(ev, ev)) / dot3(dc, dc);
+      float best2 = INFINITY;
+      {   /* like the trace pass, the walk starts at the root's children whatever the root record's value is */
+        beam_frame st[MAX_DEPTH + 1];
+        int sp = 0;
+        st[0].base = (uint32_t)root.cp; st[0].mask = root.leafMask; st[0].x = 1.0f; st[0].y = 1.0f; st[0].z = 1.0f; st[0].next = 0;
+        while (sp >= 0) {
+          beam_frame *f = &st[sp];
+          if (f->next == 8) { sp--; continue; }
+          const float size = u2f((uint32_t)(127 - (sp + 1)) << 23);   /* edge of a child cube at depth sp + 1 */
+          /* nearest octant first (the minimum does not depend on the order; the pruning does): slot k looks at child
+             k ^ near, near = the octant of this cube that holds / faces the camera */
+          const int near = (o.x >= f->x + size ? 1 : 0) | (o.y >= f->y + size ? 2 : 0) | (o.z >= f->z + size ? 4 : 0);
+          const int nch = (f->next++) ^ near;
+          nvisit++;
+          uint32_t ptr = f->base;                                      /* walk to child nch (svotrace.comp:135-145) */
+          for (int i = 0; i < nch; i++) {
+            const int tg = (f->mask >> (2 * i)) & 3;
+            ptr += tg == 1 ? LEAF_SIZE : (tg == 3 ? NON_SURFACE_LEAF_SIZE : NODE_SIZE);
+          }
+          const int tag = (f->mask >> (2 * nch)) & 3;
+          if (get_byte(&c, ptr) == 0) continue;                        /* empty */
+          const float lx = f->x + (float)(nch & 1) * size, ly = f->y + (float)((nch >> 1) & 1) * size,
+                      lz = f->z + (float)((nch >> 2) & 1) * size;
+          const float half = 0.5f * size;
+          const float mx = (lx + half) - o.x, my = (ly + half) - o.y, mz = (lz + half) - o.z;   /* cube centre, camera-relative */
+          int outside = 0;
+          for (int k = 0; k < 4 && !outside; k++) {
+            const float far = dot3(n[k], v3(mx, my, mz)) + (fabsf(n[k].x) + (fabsf(n[k].y) + fabsf(n[k].z))) * half;
+            if (far < 0.0f) outside = 1;                                /* every corner is behind this side plane */
+          }
+          if (outside) continue;
+          const float ddx = gmax(gmax(lx - o.x, o.x - (lx + size)), 0.0f), ddy = gmax(gmax(ly - o.y, o.y - (ly + size)), 0.0f),
+                      ddz = gmax(gmax(lz - o.z, o.z - (lz + size)), 0.0f);
+          const float dist2 = ddx * ddx + (ddy * ddy + ddz * ddz);
+          if (!(dist2 < best2)) continue;                               /* cannot improve the bound */
+          int cp = 0, cmask = 0;
+          if (tag == 0) {
+            const Node ch = extract_node(&c, ptr);
+            cp = ch.cp; cmask = ch.leafMask;
+          }
+          const int terminal = tag != 0 || cp == 0 || sp + 1 >= MAX_DEPTH || size * size <= dist2 * spread2;
+          if (terminal) { best2 = dist2; continue; }
+          sp++;
+          st[sp].base = ptr + (uint32_t)cp; st[sp].mask = cmask; st[sp].x = lx; st[sp].y = ly; st[sp].z = lz; st[sp].next = 0;
+        }
+      }
+      *out = sqrtf(best2) * 0.9990234375f;
+    }
+  if (visits) *visits = nvisit;
   return 0;
 }
 

@@ -170,9 +170,11 @@ struct WaveStack {
   uint16_t mk[kStackLevels * 64];
 };
 
+// t_start: 0 for every ray of the reference; the primary ray of a pixel starts at its block's beam distance when the
+// beam pre-pass is on (svo_beam.hip.h) -- same origin and coefficients, only t_min is raised
 template <bool kCount>
 __device__ __forceinline__ Cast cast_ray(const Pool &pool, WaveStack &stk, const uint32_t lane, V3 o, V3 d,
-                                         int max_depth, const bool cone, Counters &cnt) {
+                                         int max_depth, const bool cone, Counters &cnt, const float t_start = 0.0f) {
   Cast res;
   res.hit = false; res.capped = false; res.pointer = 0; res.value = 0; res.raw = 0; res.level = 0;
   res.normal = mk(0.f, 0.f, 0.f); res.voxel_pos = mk(0.f, 0.f, 0.f);
@@ -199,6 +201,7 @@ __device__ __forceinline__ Cast cast_ray(const Pool &pool, WaveStack &stk, const
   float t_min = fmax_g(fmax_g(2.0f * cx - bx, 2.0f * cy - by), 2.0f * cz - bz);
   float t_max = fmin_g(fmin_g(cx - bx, cy - by), cz - bz);
   t_min = fmax_g(t_min, 0.0f);
+  t_min = fmax_g(t_min, t_start);
   float h = t_max;
 
   uint32_t idx = 0;

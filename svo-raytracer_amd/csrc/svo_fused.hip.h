@@ -17,6 +17,11 @@ struct PathState {
   bool hit; uint32_t pointer, value, raw, level, iter; float t;
 };
 
+// start distance of pixel (px, py)'s primary ray: its block's entry of the beam image, or 0
+__device__ __forceinline__ float beam_start(const Frame &f, int px, int py) {
+  return f.use_beam ? f.beam[(size_t)(py >> 2) * (size_t)f.beam_w + (size_t)(px >> 2)] : 0.0f;
+}
+
 __device__ __forceinline__ V3 sky_colour(V3 d) {
   return mk(0.6725f - d.y * 0.4f, 0.8784f - d.y * 0.4f, 1.0f - d.y * 0.25f);
 }
@@ -51,7 +56,7 @@ __device__ __forceinline__ V3 scatter(V3 d, V3 normal, float r, bool mirror) {
 template <bool kCount>
 __device__ __forceinline__ void trace_sample(const Pool &pool, WaveStack &stk, uint32_t lane, const Frame &f, V3 o,
                                              V3 d, float seed0, float seed1, float seed2, PathState &ps, bool first,
-                                             V3 &out_colour, float &out_depth, Counters &cnt) {
+                                             V3 &out_colour, float &out_depth, Counters &cnt, const float t_start) {
   const int mode = f.render_mode;
   V3 colour = mk(0.f, 0.f, 0.f);
   float depth = 0.0f;
@@ -62,7 +67,7 @@ __device__ __forceinline__ void trace_sample(const Pool &pool, WaveStack &stk, u
     uint32_t value = 0;
     const float r = pixel_rand(seed0, seed1, seed2);
     for (int i = 0; i < f.bounces; i++) {
-      const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, i != 0, cnt);
+      const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, i != 0, cnt, i == 0 ? t_start : 0.0f);
       if (i == 0 && first) record_first(ps, c);
       if (!c.hit && i == 0) {
         const V3 s = sky_colour(d);
@@ -91,14 +96,14 @@ __device__ __forceinline__ void trace_sample(const Pool &pool, WaveStack &stk, u
     }
     colour = accum;
   } else if (mode == 1) {
-    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt);
+    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt, t_start);
     if (first) record_first(ps, c);
     depth = c.hit ? c.t : 0.0f;
     if (c.hit) { const float g = 0.005f * (float)c.iter; colour = mk(g, g, g); }
     else if (c.capped) colour = mk(0.3f, 0.3f, 0.6f);
     else { const float g = 0.01f * (float)c.iter; colour = mk(g, g, g); }
   } else if (mode == 2) {
-    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt);
+    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt, t_start);
     if (first) record_first(ps, c);
     if (c.hit) {
       depth = c.t;
@@ -126,7 +131,7 @@ __device__ __forceinline__ void trace_sample(const Pool &pool, WaveStack &stk, u
       colour = sky_colour(d);
     }
   } else if (mode == 3) {
-    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt);
+    const Cast c = cast_ray<kCount>(pool, stk, lane, o, d, kMaxDepth, false, cnt, t_start);
     if (first) record_first(ps, c);
     if (c.hit) {
       depth = c.t;
@@ -194,11 +199,12 @@ __global__ __launch_bounds__(64) void trace_fused_kernel(const uint8_t *__restri
     V3 fin = mk(0.f, 0.f, 0.f);
     float depth = 0.0f;
     const int spp = f.spp < 1 ? 1 : f.spp;
+    const float t_start = beam_start(f, px, py);
     for (int s = 0; s < spp; s++) {
       V3 col;
       float dep;
       trace_sample<kCount>(pool, stk, lane, f, o, d, (float)px, (float)py, (float)(f.frame_number + s), ps, s == 0, col,
-                           dep, cnt);
+                           dep, cnt, t_start);
       if (s == 0) depth = dep;
       fin = mk(fin.x + col.x, fin.y + col.y, fin.z + col.z);
     }

@@ -14,6 +14,7 @@
 #include "svo_persistent.hip.h"
 #include "svo_wavefront.hip.h"
 #include "svo_build.hip.h"
+#include "svo_beam.hip.h"
 
 using namespace svo;
 
@@ -46,6 +47,13 @@ struct svo_ctx {
   float *own_depth = nullptr;
   uint4 *own_hits = nullptr;
   DeviceCounters *d_counters = nullptr;
+  // beam images: one per frame in flight, re-used round-robin behind the event of the frame that read it last
+  static constexpr int kBeamSets = 8;
+  float *d_beam[kBeamSets] = {};
+  hipEvent_t beam_done[kBeamSets] = {};
+  bool beam_used[kBeamSets] = {};
+  size_t beam_cap = 0;
+  unsigned beam_frames = 0;
   WavefrontBuffers wf;
   PersistBuffers pb;
   svo_stats stats{};
@@ -93,6 +101,12 @@ static void free_outputs(svo_ctx *c) {
   if (!c->external_outputs) { c->d_color = nullptr; c->d_depth = nullptr; c->d_hits = nullptr; }
   wavefront_free(c->wf);
   persist_free(c->pb);
+  for (int i = 0; i < svo_ctx::kBeamSets; i++) {
+    if (c->d_beam[i]) (void)hipFree(c->d_beam[i]);
+    c->d_beam[i] = nullptr;
+    c->beam_used[i] = false;
+  }
+  c->beam_cap = 0;
 }
 
 int svo_destroy(svo_ctx *c) {
@@ -102,6 +116,7 @@ int svo_destroy(svo_ctx *c) {
   free_outputs(c);
   if (c->d_pool) (void)hipFree(c->d_pool);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  for (auto &e : c->beam_done) if (e) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -382,6 +397,7 @@ static int make_frame(svo_ctx *c, Frame &f) {
   f.tiles_y = c->n_tile_rows < 0 ? (f.y1 - f.y0 + 7) / 8 : c->n_tile_rows;
   f.ntiles = f.tiles_x * f.tiles_y;
   f.write_hits = (c->write_hits && c->d_hits) ? 1 : 0;
+  f.use_beam = 0; f.beam_w = 0; f.beam = nullptr;
   if (!c->external_outputs && c->n_tile_rows > 0) {
     // packed stripes land at output rows out_y0 + 8 j + ly: they must stay inside the library's W x H images
     // (caller-owned gather buffers are the caller's to size, see svo_bind_outputs)
@@ -404,11 +420,54 @@ static size_t out_elems(const svo_ctx *c, const Frame &f) {
   return std::max((size_t)c->width * (size_t)c->height, (size_t)(f.out_y0 + f.tiles_y * 8) * (size_t)c->width);
 }
 
+// the coarse pass of useBeamOptimization (Main.java:257-266), enqueued in front of the frame's trace kernels
+static int launch_beam(svo_ctx *c, Frame &f, int &set) {
+  const int bw = (f.width + kBeamBlock - 1) / kBeamBlock, bh = (f.height + kBeamBlock - 1) / kBeamBlock;
+  const size_t need = (size_t)bw * (size_t)bh;
+  if (c->beam_cap < need) {
+    HIPCHK(c, hipDeviceSynchronize());
+    for (int i = 0; i < svo_ctx::kBeamSets; i++) {
+      if (c->d_beam[i]) (void)hipFree(c->d_beam[i]);
+      c->d_beam[i] = nullptr;
+      c->beam_used[i] = false;
+      HIPCHK(c, hipMalloc((void **)&c->d_beam[i], need * sizeof(float)));
+      if (!c->beam_done[i]) HIPCHK(c, hipEventCreateWithFlags(&c->beam_done[i], hipEventDisableTiming));
+    }
+    c->beam_cap = need;
+  }
+  set = (int)(c->beam_frames++ % svo_ctx::kBeamSets);
+  if (c->beam_used[set]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->beam_done[set], 0));
+  BeamArgs a;
+  a.pool = c->d_pool; a.f = f; a.beam = c->d_beam[set]; a.beam_w = bw; a.beam_h = bh;
+  a.cam_ok = beam_camera_ok(f.cam);
+  hipLaunchKernelGGL(beam_kernel, dim3((unsigned)((bw + 7) / 8), (unsigned)(f.tiles_y * 2)), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  f.use_beam = 1; f.beam_w = bw; f.beam = c->d_beam[set];
+  return SVO_OK;
+}
+
+static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count);
+
 static int launch_frame(svo_ctx *c, bool count) {
   Frame f;
   int rc = make_frame(c, f);
   if (rc) return rc;
   if (f.ntiles <= 0) return SVO_OK;
+  int beam_set = -1;
+  if (c->use_beam) {
+    rc = launch_beam(c, f, beam_set);
+    if (rc) return rc;
+  }
+  rc = launch_frame_kernels(c, f, count);
+  if (rc == SVO_OK && beam_set >= 0) {
+    HIPCHK(c, hipEventRecord(c->beam_done[beam_set], c->stream));
+    c->beam_used[beam_set] = true;
+  }
+  return rc;
+}
+
+static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count) {
+  int rc = SVO_OK;
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
   if (c->pipeline == 1 && !count) {
     rc = persist_launch(c->pb, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, out_elems(c, f), c->stream);
@@ -516,6 +575,17 @@ static int read_rows(svo_ctx *c, void *dst, const void *src, size_t elem) {
 int svo_read_color(svo_ctx *c, void *rgba8) { return c ? read_rows(c, rgba8, c->d_color, 4) : SVO_E_INVALID; }
 int svo_read_depth(svo_ctx *c, float *depth) { return c ? read_rows(c, depth, c->d_depth, 4) : SVO_E_INVALID; }
 int svo_read_hits(svo_ctx *c, svo_hit *hits) { return c ? read_rows(c, hits, c->d_hits, 16) : SVO_E_INVALID; }
+
+int svo_read_beam(svo_ctx *c, float *beam) {
+  if (!c || !beam) return fail(c, SVO_E_INVALID, "svo_read_beam: null buffer");
+  if (!c->beam_frames || !c->beam_cap) return fail(c, SVO_E_INVALID, "svo_read_beam: no frame was dispatched with use_beam");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int set = (int)((c->beam_frames - 1) % svo_ctx::kBeamSets);
+  const size_t n = (size_t)((c->width + kBeamBlock - 1) / kBeamBlock) * (size_t)((c->height + kBeamBlock - 1) / kBeamBlock);
+  HIPCHK(c, hipMemcpy(beam, c->d_beam[set], std::min(n, c->beam_cap) * sizeof(float), hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
 
 int svo_read_pixel(svo_ctx *c, int x, int y, void *rgba8, float *depth, svo_hit *hit) {
   if (!c) return SVO_E_INVALID;

@@ -19,6 +19,9 @@ struct Frame {
   uint32_t dword0;      // first dword of the pool (debug square colour, svotrace.comp:696-698)
   int32_t tiles_x, tiles_y, ntiles;
   int32_t write_hits;
+  // beam pre-pass (useBeamOptimization, Main.java:257-283): start distance per 4x4 pixel block, or off
+  int32_t use_beam, beam_w;
+  const float *beam;
 };
 
 // device-side counters of a counted frame

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             value = 0u;
             depth = 0.0f;
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
-            status = SVO_TRAV_INIT(root, t, cam_o, d, false);
+            status = SVO_TRAV_INIT(root, t, cam_o, d, false, beam_start(f, px, py));
           }
         }
         if (base + n >= band_total) {  // this band is used up: move on (work stealing)

@@ -75,7 +75,7 @@ enum : int { ST_SKIP = -1, ST_IDLE = 0, ST_ACTIVE = 1, ST_HIT = 2, ST_MISS = 3, 
 
 // set-up part of the cast (svotrace.comp:221-260)
 // `root` = the root record (svotrace.comp:222), fetched once per wave by the caller
-__device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 d, const bool cone) {
+__device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 d, const bool cone, const float t_start = 0.0f) {
   t.cone_t = cone ? 0.05f : __builtin_inff();
   t.iter = 0; t.cptr = 0; t.tag = 0; t.rlo = 0; t.rhi = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
@@ -98,6 +98,7 @@ __device__ __forceinline__ int trav_init(const uint64_t root, Trav &t, V3 o, V3 
   t.t_min = vmax3(2.0f * t.cx - t.bx, 2.0f * t.cy - t.by, 2.0f * t.cz - t.bz);
   t.t_max = vmin3(t.cx - t.bx, t.cy - t.by, t.cz - t.bz);
   t.t_min = vmax(t.t_min, 0.0f);
+  t.t_min = vmax(t.t_min, t_start);   // beam pre-pass: the walk starts further along the same ray
   t.h = t.t_max;
   t.idx = 0; t.px = 1.0f; t.py = 1.0f; t.pz = 1.0f;
   if (1.5f * t.cx - t.bx > t.t_min) { t.idx ^= 1u; t.px = 1.5f; }

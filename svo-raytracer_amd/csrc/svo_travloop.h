@@ -52,7 +52,8 @@ struct TravRegs {
 
 // set-up part of the cast (svotrace.comp:221-260)
 // `root` = the root record (svotrace.comp:222), fetched once per wave by the caller
-__device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, V3 o, V3 d, const bool cone) {
+__device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, V3 o, V3 d, const bool cone,
+                                              const float t_start = 0.0f) {
   t.cone_t = cone ? 0.05f : __builtin_inff();
   t.iter = 0; t.cptr = 0; t.tag = 0; t.rlo = 0; t.rhi = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
@@ -75,6 +76,7 @@ __device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, 
   t.t_min = vmax3(2.0f * t.cx - t.bx, 2.0f * t.cyz.x - t.byz.x, 2.0f * t.cyz.y - t.byz.y);
   t.t_max = vmin3(t.cx - t.bx, t.cyz.x - t.byz.x, t.cyz.y - t.byz.y);
   t.t_min = vmax(t.t_min, 0.0f);
+  t.t_min = vmax(t.t_min, t_start);   // beam pre-pass: the walk starts further along the same ray
   t.h = t.t_max;
   t.idx = 0; t.px = 1.0f; t.pyz.x = 1.0f; t.pyz.y = 1.0f;
   if (1.5f * t.cx - t.bx > t.t_min) { t.idx ^= 1u; t.px = 1.5f; }

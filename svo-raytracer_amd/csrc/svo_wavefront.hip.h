@@ -171,9 +171,16 @@ __global__ __launch_bounds__(64, SVO_TRACE_WAVES_PER_SIMD) void wf_trace_kernel(
           slot = band * cap + idx;
           const uint4 q0 = a.rays_in[2 * (size_t)slot];
           const uint4 q1 = a.rays_in[2 * (size_t)slot + 1];
-          if (q0.x != 0xffffffffu)
+          if (q0.x != 0xffffffffu) {
+            float t_start = 0.0f;
+            if (kPrimary && f.use_beam) {   // pixel coordinates from the output index, as the shade kernel does
+              const int oyl = (int)(q0.x / (uint32_t)f.width) - f.out_y0;
+              t_start = beam_start(f, (int)(q0.x % (uint32_t)f.width), frame_gy(f, oyl >> 3, oyl & 7));
+            }
             status = trav_init(root, t, mk(__uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)),
-                               mk(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)), (q1.w & 1u) != 0u);
+                               mk(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)), (q1.w & 1u) != 0u,
+                               t_start);
+          }
         }
         if (base + n >= band_total) {  // band used up: steal from the next one
           band = (band + 1u) & 7u;

@@ -16,7 +16,7 @@ EXPORTS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
     "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
-    "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel",
+    "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel", "svo_read_beam",
     "svo_output_device_ptrs",
 ]
 
@@ -79,6 +79,7 @@ def lib(path=None):
         L.svo_read_color.argtypes = [vp, vp]
         L.svo_read_depth.argtypes = [vp, vp]
         L.svo_read_hits.argtypes = [vp, vp]
+        L.svo_read_beam.argtypes = [vp, vp]
         L.svo_read_pixel.argtypes = [vp, ci, ci, vp, vp, vp]
         L.svo_output_device_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
         for n in EXPORTS:
@@ -234,6 +235,11 @@ class HipContext:
         self._chk(self._L.svo_read_hits(self._h, out.ctypes.data))
         return out
 
+    def read_beam(self):
+        out = np.zeros(((self.height + 3) // 4, (self.width + 3) // 4), dtype=np.float32)
+        self._chk(self._L.svo_read_beam(self._h, out.ctypes.data))
+        return out
+
     def read_pixel(self, x, y):
         rgba = np.zeros(4, dtype=np.uint8)
         depth = np.zeros(1, dtype=np.float32)
@@ -248,13 +254,13 @@ class HipContext:
 
     # convenience used by tests / bench: one full frame, everything read back
     def render(self, pool=None, width=None, height=None, cam=None, frame_number=2, render_mode=2, bounces=2,
-               mirror_mask=0, spp=1):
+               mirror_mask=0, spp=1, use_beam=0):
         if pool is not None:
             self.pool_upload(pool)
         if width is not None:
             self.resize(width, height)
         if cam is not None:
             self.set_camera(cam)
-        self.set_params(frame_number, render_mode, 0, 0, bounces, mirror_mask, spp)
+        self.set_params(frame_number, render_mode, 0, use_beam, bounces, mirror_mask, spp)
         self.dispatch()
         return {"rgba": self.read_color(), "depth": self.read_depth(), "hits": self.read_hits()}
