@@ -283,7 +283,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #if SVO_ASM_LOOP
     {
       const unsigned long long act = __ballot(status == ST_ACTIVE);
-      trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold));
+      // cone rays: the secondary segments of a GI path (svotrace.comp:446: coneTrace = i != 0)
+      trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold),
+                kMode == 0 ? __ballot(seg != 0u) : 0ull);
     }
 #else
     for (;;) {

@@ -6,18 +6,24 @@
 // cycles, a SIMD retires a wave64 VALU instruction every ~2.5 (tools/calib_valu.hip), and every
 // trip executes the descend, advance and pop sections one after the other for whichever lanes
 // need them.  hipcc's version of the loop is 123 vector instructions per trip (phi copies on the
-// back edge, status bookkeeping in a VGPR, hazard nops); this one is 100 (+ 29 scalar / branch):
-//   * lane sets (active / hit / descend / advance / pop) live in SGPR pairs and are combined
+// back edge, status bookkeeping in a VGPR, hazard nops); this one is 96 (+ 30 scalar / branch):
+//   * lane sets (active / hit / descend / advance / pop / cone rays) live in SGPR pairs and are combined
 //     on the scalar unit, the record-independent part before the wait; the status VGPR is only
 //     written when a lane stops; the rare exits (iteration cap, leaving the octree) are out of line;
-//   * the three per-axis comparisons feed carry chains (v_addc_co_u32) that build the 3-bit
-//     child index, and selected increments (0 or the cell size) that update the position in
-//     place -- no old/new copies of the position;
+//   * the child index is not carried from trip to trip: a cell's origin is a multiple of its size, so the
+//     index is bit `scale` of the three position components (3 bit-field extracts + 2 shift-ors at the top
+//     of a trip; the descend and pop sections need not rebuild it, the advance section tests
+//     step & ~index instead of updating it: -4 instructions per trip, +1.0 % frames/s);
+//   * the three per-axis comparisons of a step select increments (0 or the cell size) that update the
+//     position in place -- no old/new copies of the position; a carry chain (v_addc_co_u32) builds the
+//     step mask;
 //   * the advance step of every active lane is computed while the record is in flight;
 //   * the record comes in two dword loads (34 cycles each in the texture path for a divergent
 //     wave, any alignment) instead of one misaligned dwordx2 (96 cycles, tools/calib_td.hip);
 //   * the pushed {child-block base, t_max} pair goes to LDS with one ds_write2_b32 from the two
 //     registers where they live.
+// Tried and dropped here: asking for the first line of the child block as soon as a descend is decided (a third
+// buffer_load_dword per trip into a register nobody reads): -9 % -- the texture path is the busier unit.
 // Arithmetic, operand order and rounding are those of trav_step(); the parity tests run both.
 //
 // Hazards observed (gfx950): a VALU write of an SGPR pair / VCC needs two other instructions
@@ -35,12 +41,12 @@ namespace svo {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+
 // per-ray constants and state in the register layout of trav_loop()
 struct TravRegs {
   float cx, bx;
   f32x2 cyz, byz;
   uint32_t octant;
-  float cone_t;
   float px;
   f32x2 pyz;
   float t_min, t_max, sexp, h;
@@ -54,7 +60,7 @@ struct TravRegs {
 // `root` = the root record (svotrace.comp:222), fetched once per wave by the caller
 __device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, V3 o, V3 d, const bool cone,
                                               const float t_start = 0.0f) {
-  t.cone_t = cone ? 0.05f : __builtin_inff();
+  (void)cone;   // which lanes carry cone (secondary) rays is a lane set the caller passes to trav_loop
   t.iter = 0; t.cptr = 0; t.tag = 0; t.rlo = 0; t.rhi = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
   if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
@@ -135,8 +141,10 @@ __device__ __forceinline__ uint32_t lds_offset(T *p) {
 
 // Run trips until at most `threshold` lanes of `act` (the lanes with status == ST_ACTIVE) are still traversing.
 // Lanes that stop get their status (ST_HIT / ST_MISS / ST_CAPPED); r.rlo/r.rhi are then the hit record.
+// `cone_lanes`: the lanes whose ray is a cone (secondary) ray -- they drop to LOD 11 once t_min > 0.05 (svotrace.comp:275-277).
 __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, const uint32_t lane, TravRegs &r,
-                                          int &status, unsigned long long act, const int threshold) {
+                                          int &status, unsigned long long act, const int threshold,
+                                          const unsigned long long cone_lanes) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
   const uint32_t lds2 = lds_offset(&stk.mk[lane]);
   unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh;
@@ -148,6 +156,13 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "Ltrip%=:\n\t"
       "s_mov_b64 exec, %[act]\n\t"
       // ---- child slot, iteration cap (svotrace.comp:263-266)
+      // the child index is not carried: it is the bit `scale` of the three position components (a cell's origin is a
+      // multiple of its size), so the descend / pop sections need not rebuild it
+      "v_bfe_u32 %[t0], %[px], %[scale], 1\n\t"
+      "v_bfe_u32 %[t1], v68, %[scale], 1\n\t"
+      "v_bfe_u32 %[t2], v69, %[scale], 1\n\t"
+      "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"
+      "v_lshl_or_b32 %[idx], %[t2], 2, %[t0]\n\t"                // idx = x | y << 1 | z << 2
       "v_xor_b32 %[t0], %[idx], %[oct]\n\t"                       // cs = idx ^ octant
       "v_add_u32 %[iter], 1, %[iter]\n\t"                         // iter++
       "v_lshlrev_b32 %[t1], 1, %[t0]\n\t"                     // 2 cs
@@ -173,12 +188,13 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       // ---- exit distances of the current cell (svotrace.comp:268-269)
       "v_mul_f32 %[tcx], %[px], %[cx]\n\t"
       "v_pk_mul_f32 v[86:87], v[68:69], %[cyz]\n\t"
-      "v_cmp_gt_f32 vcc, %[tmin], %[cone]\n\t"                    // t_min > cone_t: cone rays drop to LOD 11 (sticky)
+      "v_cmp_lt_f32 vcc, %[k005], %[tmin]\n\t"                    // t_min > 0.05 ...
       "v_sub_f32 %[tcx], %[tcx], %[bx]\n\t"
       "v_pk_add_f32 v[86:87], v[86:87], %[byz] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_and_b64 vcc, vcc, %[conem]\n\t"                          // ... on a cone (secondary) ray: LOD 11 from here on (sticky)
       "v_cmp_le_f32_e64 %[sa], %[tmin], %[tmax]\n\t"              // t_min <= t_max
-      "v_cndmask_b32_e64 %[lod], %[lod], 12, vcc\n\t"
       "v_min3_f32 %[tcm], %[tcx], v86, v87\n\t"                 // tc_max
+      "v_cndmask_b32_e64 %[lod], %[lod], 12, vcc\n\t"
       "v_min_f32 %[t3], %[tmax], %[tcm]\n\t"                       // tv_max
       "v_cmp_eq_u32_e64 %[sb], %[scale], %[lod]\n\t"              // at the LOD scale
       "v_cmp_le_f32_e64 %[sc], %[tmin], %[t3]\n\t"              // t_min <= tv_max
@@ -239,9 +255,6 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_cndmask_b32_e64 %[t0], 0, v72, vcc\n\t"
       "v_cndmask_b32_e64 v92, 0, v72, %[sb]\n\t"
       "v_cndmask_b32_e64 v93, 0, v72, %[sc]\n\t"
-      "v_cndmask_b32_e64 %[idx], 0, 1, %[sc]\n\t"
-      "v_addc_co_u32_e64 %[idx], %[sf], %[idx], %[idx], %[sb]\n\t"
-      "v_addc_co_u32_e64 %[idx], %[sf], %[idx], %[idx], vcc\n\t"   // idx = 4 z + 2 y + x
       "v_add_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[68:69], v[68:69], v[92:93]\n\t"
       "v_add_u32 %[scale], -1, %[scale]\n\t"
@@ -254,8 +267,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_mov_b32 %[tmin], %[tcm]\n\t"                            // t_min = tc_max
       "v_sub_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[68:69], v[68:69], v[92:93] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_xor_b32 %[idx], %[idx], %[t2]\n\t"
-      "v_and_b32 %[t2], %[idx], %[t2]\n\t"
+      "v_bitop3_b32 %[t2], %[t2], %[idx], %[idx] bitop3:0x30\n\t"   // step & ~idx: an axis stepped out of the lower half
       "v_cmp_ne_u32 vcc, 0, %[t2]\n\t"                      // left the parent: POP
       "s_mov_b64 exec, vcc\n\t"
       "s_cbranch_execz LnoA%=\n\t"
@@ -281,11 +293,6 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_and_b32 %[px], %[px], %[t3]\n\t"                       // round the position to the cell
       "v_and_b32 v68, v68, %[t3]\n\t"
       "v_and_b32 v69, v69, %[t3]\n\t"
-      "v_bfe_u32 %[idx], %[px], %[scale], 1\n\t"
-      "v_bfe_u32 %[t0], v68, %[scale], 1\n\t"
-      "v_bfe_u32 %[t3], v69, %[scale], 1\n\t"
-      "v_lshl_or_b32 %[idx], %[t0], 1, %[idx]\n\t"
-      "v_lshl_or_b32 %[idx], %[t3], 2, %[idx]\n\t"                // idx from the position bits
       "v_cmp_le_u32 vcc, 23, %[scale]\n\t"                     // left the octree: MISS
       "s_waitcnt lgkmcnt(0)\n\t"
       "v_and_b32 %[pbase], %[t2], v92\n\t"
@@ -317,7 +324,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
         "=&{v88}"(r.rlo), "=&{v89}"(r.rhi), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
         [t3] "=&v"(t3), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd),
         [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh), [cnt] "=&s"(cnt)
-      : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [cone] "v"(r.cone_t),
+      : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
         [lds8] "v"(lds8), [lds2] "v"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
         [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
       : "vcc", "scc", "memory", "v73", "v86", "v87", "v92", "v93");

@@ -217,3 +217,32 @@ def test_config5_8192_1080p_64_samples_per_pixel():
         assert not np.array_equal(one["rgba"], res["rgba"])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_iteration_cap_inside_the_traversal_loop(ctx, pipeline):
+    """Rays that skim a flat 4096^2 plateau half a voxel above it cross thousands of empty unit cells: the walk gives up
+    after 1500 iterations (svotrace.comp:263-266) -- renderMode 1 paints those pixels (0.3, 0.3, 0.6), mode 2's shadow
+    term reads the count.  The plateau is built by the GPU builder; the oracle renders the downloaded pool."""
+    from oracle import oracle
+    n = 4096
+    h = np.full((n, n), n // 2, dtype=np.uint16)
+    m = np.full((n, n), 2, dtype=np.uint8)
+    nbytes = ctx.build_from_heightmap(h, m)
+    pool = ctx.pool_download(nbytes)
+    y = 1.0 + (n // 2 + 1.5) / n                      # half a voxel above the plateau's top face
+    pos = (1.0 + 0.25 / n, y, 1.5)
+    cam = np.array(pos + (1.0, -0.0004, -0.3) + (1.0, 0.0004, -0.3) + (1.0, -0.0004, 0.3) + (1.0, 0.0004, 0.3), dtype=np.float32)
+    ctx.set_pipeline(pipeline)
+    w, hh = 96, 64
+    for mode in (1, 2, 0):
+        got = ctx.render(None, w, hh, cam, 2, mode)
+        ref = oracle.render(pool, w, hh, cam, 2, mode)
+        bad = _same(got, ref)
+        assert bad == {k: 0 for k in bad}, (mode, bad)
+        if mode == 1:
+            capped = int((ref["hits"]["iter"] > 1500).sum())
+            assert capped > 200, capped                # the cap really is reached inside the loop
+            cm = ref["hits"]["iter"] > 1500
+            cm[:10, :10] = False                       # the debug square overwrites the corner
+            assert (ref["rgba"][cm][:, :3] == [76, 76, 153]).all()
