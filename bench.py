@@ -114,7 +114,7 @@ def source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "svo-raytracer_amd", "csrc")
     for n in sorted(os.listdir(d)):
-        if n.endswith((".h", ".hip", ".cpp")) or n == "Makefile":
+        if n.endswith((".h", ".hip")) or n == "Makefile":   # kernels + their build flags (not the forwarding JNI shim)
             h.update(n.encode())
             h.update(open(os.path.join(d, n), "rb").read())
     return h.hexdigest()[:16]

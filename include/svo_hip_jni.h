@@ -51,6 +51,12 @@ jint Java_src_engine_HipRenderer_nReadHits(void *env, void *cls, jlong ctx, jlon
 /* the crosshair pick of Main.java:132-146 without the full-frame readback: addresses of 4 / 4 / 16 bytes, 0 = skip */
 jint Java_src_engine_HipRenderer_nReadPixel(void *env, void *cls, jlong ctx, jint x, jint y, jlong rgba_addr,
                                             jlong depth_addr, jlong hit_addr);
+/* image unit 2 of the reference (Main.java:79-86): ceil(H/4) x ceil(W/4) floats */
+jint Java_src_engine_HipRenderer_nReadBeam(void *env, void *cls, jlong ctx, jlong addr);
+/* Octree.constructCompleteOctree (Octree.java:192-353) on the GPU: addresses of n*n u16 heights (voxels) and n*n u8
+ * materials; returns the new pool's size in bytes (what Octree.memOffset would be), or a negative status */
+jlong Java_src_engine_HipRenderer_nBuildFromHeightmap(void *env, void *cls, jlong ctx, jlong height_addr,
+                                                      jlong material_addr, jint n);
 
 #ifdef __cplusplus
 }

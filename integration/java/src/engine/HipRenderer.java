@@ -161,6 +161,18 @@ public class HipRenderer {
     return d;
   }
 
+  /**
+   * Octree.constructCompleteOctree on the GPU: heights (u16, voxels) and surface materials (u8) of an n x n world,
+   * indexed [z * n + x].  The built pool becomes the bound SSBO; returns its size (the octree's memOffset) or a
+   * negative status.  getSSBO(buf) copies it into the Java-side ByteBuffer if the host needs it (SDF edits).
+   */
+  public long buildFromHeightmap(ByteBuffer heights, ByteBuffer materials, int n) {
+    long r = nBuildFromHeightmap(ctx, MemoryUtil.memAddress(heights), MemoryUtil.memAddress(materials), n);
+    if (r < 0)
+      printGLErrors();
+    return r;
+  }
+
   /** Dormant shader features (svotrace.comp:444, 500-504, 668-670); defaults = live behaviour. */
   public void setPathOptions(int bounces, int mirrorMask, int spp) {
     this.bounces = bounces;
@@ -188,5 +200,7 @@ public class HipRenderer {
   private static native int nReadColor(long ctx, long addr);
   private static native int nReadDepth(long ctx, long addr);
   private static native int nReadHits(long ctx, long addr);
+  private static native int nReadBeam(long ctx, long addr);
+  private static native long nBuildFromHeightmap(long ctx, long heightAddr, long materialAddr, int n);
   private static native int nReadPixel(long ctx, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);
 }

@@ -53,5 +53,14 @@ jint Java_src_engine_HipRenderer_nReadPixel(void *, void *, jlong ctx, jint x, j
   return svo_read_pixel((svo_ctx *)(intptr_t)ctx, x, y, (void *)(intptr_t)rgba_addr, (float *)(intptr_t)depth_addr,
                         (svo_hit *)(intptr_t)hit_addr);
 }
+jint Java_src_engine_HipRenderer_nReadBeam(void *, void *, jlong ctx, jlong addr) {
+  return svo_read_beam((svo_ctx *)(intptr_t)ctx, (float *)(intptr_t)addr);
+}
+jlong Java_src_engine_HipRenderer_nBuildFromHeightmap(void *, void *, jlong ctx, jlong height_addr, jlong material_addr, jint n) {
+  uint64_t nbytes = 0;
+  const int rc = svo_build_from_heightmap((svo_ctx *)(intptr_t)ctx, (const uint16_t *)(intptr_t)height_addr,
+                                          (const uint8_t *)(intptr_t)material_addr, n, &nbytes);
+  return rc == SVO_OK ? (jlong)nbytes : (jlong)rc;   // the pool's size (memOffset), or a negative status
+}
 
 }  // extern "C"

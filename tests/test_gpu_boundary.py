@@ -59,6 +59,8 @@ def test_jni_shim_called_with_jni_typed_arguments(ctx):
     nReadDepth = fn("nReadDepth", jint, jlong, jlong)
     nReadHits = fn("nReadHits", jint, jlong, jlong)
     nReadPixel = fn("nReadPixel", jint, jlong, jint, jint, jlong, jlong, jlong)
+    nReadBeam = fn("nReadBeam", jint, jlong, jlong)
+    nBuildFromHeightmap = fn("nBuildFromHeightmap", jlong, jlong, jlong, jlong, jint)
 
     pool, _ = scene.build_scene(128)
     cam = np.asarray(CAMERAS["K1"], dtype=np.float32)
@@ -105,6 +107,17 @@ def test_jni_shim_called_with_jni_typed_arguments(ctx):
         assert nDispatch(j) == 0 and nReadColor(j, rgba.ctypes.data) == 0
         want2 = ctx.render(edited, w, h, cam, 3, 0)
         assert (rgba == want2["rgba"]).all()
+        # world generation and the beam image through the shim
+        hm, mm = scene.scene_maps(128)
+        assert nBuildFromHeightmap(j, hm.ctypes.data, mm.ctypes.data, 128) == pool.size
+        assert nPoolDownload(j, back.ctypes.data, back.size) == 0 and (back == pool).all()
+        assert nBuildFromHeightmap(j, hm.ctypes.data, mm.ctypes.data, 100) < 0        # not a power of two
+        assert nSetParams(j, 3, 0, int(pool.size), 1, 2, 0, 1) == 0 and nDispatch(j) == 0
+        beam = np.zeros(((h + 3) // 4, (w + 3) // 4), dtype=np.float32)
+        assert nReadBeam(j, beam.ctypes.data) == 0
+        want3 = ctx.render(pool, w, h, cam, 3, 0, use_beam=1)
+        assert np.array_equal(beam.view(np.uint32), ctx.read_beam().view(np.uint32))
+        assert nReadColor(j, rgba.ctypes.data) == 0 and (rgba == want3["rgba"]).all()
     finally:
         assert nDestroy(j) == 0
 
