@@ -139,6 +139,12 @@ int svo_set_pipeline(svo_ctx *ctx, int pipeline);
  * about 10 when the caller keeps 2-3 frames in flight on alternating streams) and the refill round
  * threshold in sixteenths (0 = default 9: a round starts once 7/16 of the traversing lanes have stopped) */
 int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_sixteenths);
+/* the reference's dormant cross-frame accumulation (commented out at svotrace.comp:712-719; MAX_FRAME_ITER :43):
+ * when enabled and frameNumber > 1, a pixel's colour becomes (frameNumber * last + colour) / (frameNumber + 1), `last`
+ * being what the colour image holds from the previous dispatch (rgba8, as imageLoad returns it), and stays `last` from
+ * frameNumber 100 on.  Default off = the live shader.  The caller keeps rendering into the same colour image and
+ * resets frameNumber when the camera moves, as Main.java does (:16, :275). */
+int svo_set_progressive(svo_ctx *ctx, int enabled);
 /* record per-pixel svo_hit (costs 16 B/pixel of stores); default on */
 int svo_set_hit_records(svo_ctx *ctx, int enabled);
 

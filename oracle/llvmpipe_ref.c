@@ -23,6 +23,10 @@
  *                               the first cast's hit pointer is exported through an
  *                               extra r32ui image (the live shader has that store
  *                               commented out, svotrace.comp:728)
+ *   accum <0|1>                 1: use the program whose dormant cross-frame accumulation
+ *                               (svotrace.comp:712-719, commented out) is switched on in memory
+ *   keep <0|1>                  1: the images persist from render to render, as in Main.java
+ *   fresh                       drop the persistent images (the next render starts from cleared ones)
  *   render <prefix>             writes <prefix>.rgba  <prefix>.depth  [<prefix>.ptr]
  *
  * Build: see oracle/Makefile (output goes to oracle/_ref/, git-ignored).
@@ -187,6 +191,46 @@ static char *apply_ptr_patch(const char *src) {
   return s4;
 }
 
+/*
+ * In-memory activation of the reference's dormant cross-frame accumulation: the block at svotrace.comp:712-719
+ * (`if(frameNumber > 1){ lastcolor = imageLoad(...); finalcolor = (frameNumber * lastcolor + finalcolor) /
+ * (frameNumber + 1) ... }`) is commented out line by line; this strips the leading "// " of exactly those lines.
+ * Addressed by line number (no shader text lives here); the first line is checked for the frameNumber test.
+ */
+static char *apply_accum_patch(const char *src, int first_line, int last_line) {
+  char *out = malloc(strlen(src) + 1), *o = out;
+  int line = 1, checked = 0;
+  const char *p = src;
+  while (*p) {
+    const char *e = strchr(p, '\n');
+    size_t n = e ? (size_t)(e - p) + 1 : strlen(p);
+    if (line >= first_line && line <= last_line) {
+      const char *c = p;
+      while (c < p + n && (*c == ' ' || *c == '\t')) c++;
+      if (c + 2 <= p + n && c[0] == '/' && c[1] == '/') {
+        if (line == first_line) {
+          char tmp[256];
+          size_t m = n < 255 ? n : 255;
+          memcpy(tmp, p, m); tmp[m] = 0;
+          checked = strstr(tmp, "frameNumber > 1") != NULL;
+        }
+        memcpy(o, p, (size_t)(c - p)); o += c - p;       /* indentation */
+        c += 2;
+        memcpy(o, c, (size_t)(p + n - c)); o += p + n - c;
+        p += n; line++;
+        continue;
+      }
+      fprintf(stderr, "accum patch: line %d is not a comment\n", line);
+      exit(2);
+    }
+    memcpy(o, p, n); o += n;
+    p += n; line++;
+  }
+  *o = 0;
+  if (!checked) { fprintf(stderr, "accum patch: line %d is not the frameNumber test\n", first_line); exit(2); }
+  return out;
+}
+
 static GLuint build_program(const char *src) {
   GLuint sh = glCreateShader(GL_COMPUTE_SHADER);
   glShaderSource(sh, 1, &src, NULL);
@@ -256,8 +300,11 @@ int main(int argc, char **argv) {
   char *src_patched = apply_ptr_patch(src);
   GLuint prog_plain = build_program(src);
   GLuint prog_patched = build_program(src_patched);
+  char *src_accum = apply_accum_patch(src, 712, 719);
+  GLuint prog_accum = build_program(src_accum);
 
-  int W = 256, H = 256, frame = 2, mode = 2, ptrpatch = 0;
+  int W = 256, H = 256, frame = 2, mode = 2, ptrpatch = 0, accum = 0, keep = 0, have_tex = 0, texW = 0, texH = 0;
+  GLuint tex[3] = {0, 0, 0};
   float cam[15] = {1.5f, 1.5f, 2.0f, -1.6f, -0.9f, -1, -1.6f, 0.9f, -1, 1.6f, -0.9f, -1, 1.6f, 0.9f, -1};
   GLuint ssbo = 0;
   size_t pool_len = 0;
@@ -294,9 +341,17 @@ int main(int argc, char **argv) {
       sscanf(line, "%*s %d", &mode);
     } else if (!strcmp(cmd, "ptrpatch")) {
       sscanf(line, "%*s %d", &ptrpatch);
+    } else if (!strcmp(cmd, "accum")) {        /* 1: the program with svotrace.comp:712-719 active */
+      sscanf(line, "%*s %d", &accum);
+    } else if (!strcmp(cmd, "keep")) {         /* 1: the images persist from render to render (Main.java allocates them once) */
+      sscanf(line, "%*s %d", &keep);
+    } else if (!strcmp(cmd, "fresh")) {        /* drop the persistent images: the next render starts from cleared ones */
+      if (have_tex) { glDeleteTextures(3, tex); have_tex = 0; }
     } else if (!strcmp(cmd, "render")) {
       sscanf(line, "%*s %4095s", arg);
-      GLuint tex[3];
+      const int reuse = keep && have_tex && texW == W && texH == H;
+      if (have_tex && !reuse) { glDeleteTextures(3, tex); have_tex = 0; }
+      if (!reuse) {
       glGenTextures(3, tex);
       glActiveTexture(GL_TEXTURE0);
       glBindTexture(GL_TEXTURE_2D, tex[0]);
@@ -316,8 +371,10 @@ int main(int argc, char **argv) {
       glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
       glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32UI, W, H);
       glBindImageTexture(3, tex[2], 0, GL_TRUE, 0, GL_READ_WRITE, GL_RGBA32UI);
+      have_tex = 1; texW = W; texH = H;
+      }
 
-      glUseProgram(ptrpatch ? prog_patched : prog_plain);
+      glUseProgram(accum ? prog_accum : (ptrpatch ? prog_patched : prog_plain));
       glUniform3fv(8, 1, cam + 0);
       glUniform3fv(1, 1, cam + 3);
       glUniform3fv(2, 1, cam + 6);
@@ -341,7 +398,7 @@ int main(int argc, char **argv) {
       glGetTexImage(GL_TEXTURE_2D, 0, GL_RED, GL_FLOAT, depth);
       write_file(arg, ".rgba", rgba, npx * 4);
       write_file(arg, ".depth", depth, npx * 4);
-      if (ptrpatch) {
+      if (ptrpatch && !accum) {
         glActiveTexture(GL_TEXTURE3);
         glBindTexture(GL_TEXTURE_2D, tex[2]);
         glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA_INTEGER, GL_UNSIGNED_INT, ptr);
@@ -350,8 +407,8 @@ int main(int argc, char **argv) {
       GLenum e = glGetError();
       if (e) fprintf(stderr, "GL error 0x%x after render %s\n", e, arg);
       free(rgba); free(depth); free(ptr);
-      glDeleteTextures(3, tex);
-      fprintf(stderr, "rendered %s %dx%d mode %d frame %d patch %d\n", arg, W, H, mode, frame, ptrpatch);
+      if (!keep) { glDeleteTextures(3, tex); have_tex = 0; }
+      fprintf(stderr, "rendered %s %dx%d mode %d frame %d patch %d accum %d\n", arg, W, H, mode, frame, ptrpatch, accum);
     }
   }
   return 0;

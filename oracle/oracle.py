@@ -19,7 +19,7 @@ class Params(ctypes.Structure):
     _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("cam", ctypes.c_float * 15),
                 ("frame_number", ctypes.c_int32), ("render_mode", ctypes.c_int32), ("buffer_end", ctypes.c_int32),
                 ("use_beam", ctypes.c_int32), ("bounces", ctypes.c_int32), ("mirror_mask", ctypes.c_uint32),
-                ("spp", ctypes.c_int32)]
+                ("spp", ctypes.c_int32), ("progressive", ctypes.c_int32)]
 
 
 class Stats(ctypes.Structure):
@@ -62,7 +62,7 @@ def lib():
     return _lib
 
 
-def _params(pool, width, height, cam, frame_number, render_mode, bounces, mirror_mask, spp):
+def _params(pool, width, height, cam, frame_number, render_mode, bounces, mirror_mask, spp, progressive=0):
     prm = Params()
     prm.width, prm.height = int(width), int(height)
     cam = np.asarray(cam, dtype=np.float32).reshape(15)
@@ -71,6 +71,7 @@ def _params(pool, width, height, cam, frame_number, render_mode, bounces, mirror
     prm.frame_number, prm.render_mode = int(frame_number), int(render_mode)
     prm.buffer_end, prm.use_beam = int(pool.size), 0
     prm.bounces, prm.mirror_mask, prm.spp = int(bounces), int(mirror_mask), int(spp)
+    prm.progressive = int(progressive)
     return prm
 
 
@@ -90,15 +91,17 @@ def beam(pool, width, height, cam, want_visits=False):
 
 
 def render(pool, width, height, cam, frame_number=2, render_mode=2, bounces=2, mirror_mask=0, spp=1,
-           rows=None, xstep=1, ystep=1, want_hits=True, use_beam=False):
+           rows=None, xstep=1, ystep=1, want_hits=True, use_beam=False, last_rgba=None):
     """Run the CPU restatement. cam: 15 floats (pos,l1,l2,r1,r2). Returns dict with
     rgba (H,W,4 u8), depth (H,W f32), hits (H,W HIT_DTYPE), stats.  use_beam: primary rays start at the coarse
     pass's distance of their block (see svo_oracle_beam in svo_oracle.c); the result also carries "beam"."""
     pool = np.ascontiguousarray(pool, dtype=np.uint8)
-    prm = _params(pool, width, height, cam, frame_number, render_mode, bounces, mirror_mask, spp)
+    prm = _params(pool, width, height, cam, frame_number, render_mode, bounces, mirror_mask, spp,
+                  progressive=last_rgba is not None)
     tb = beam(pool, width, height, cam) if use_beam else None
     y0, y1 = (0, height) if rows is None else rows
-    rgba = np.zeros((height, width, 4), dtype=np.uint8)
+    # last_rgba: the image the previous frame left (cross-frame accumulation, svotrace.comp:712-719, dormant)
+    rgba = np.zeros((height, width, 4), dtype=np.uint8) if last_rgba is None else np.array(last_rgba, dtype=np.uint8).reshape(height, width, 4).copy()
     depth = np.zeros((height, width), dtype=np.float32)
     hits = np.zeros((height, width), dtype=HIT_DTYPE) if want_hits else None
     st = Stats()

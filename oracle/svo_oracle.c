@@ -39,6 +39,12 @@
 #define MAX_DEPTH 13
 #define MAX_RAYCAST_ITERATIONS 1500u
 #define BEAM_BLOCK 4 /* Main.java:41 beamSquareSize */
+#define MAX_FRAME_ITER 100
+/* pinned by tests/golden/accum_golden.npz (the reference shader with :712-719 switched on, under llvmpipe): imageLoad of
+   an rgba8 texel is byte * (1/255) (not byte / 255: 115 pixels of the goldens tell them apart), the division by
+   frameNumber + 1 is a true IEEE division (a multiply by the reciprocal misses 48) */
+#define UNORM8_TO_FLOAT(b) ((float)(b) * (1.0f / 255.0f))
+#define PROG_DIV(a, b) ((a) / (b))
 
 typedef struct svo_hit {
   uint32_t pointer;    /* byte offset of the hit node; 0 = miss */
@@ -56,6 +62,8 @@ typedef struct svo_oracle_params {
   int32_t bounces;      /* path segments in mode 0; reference live value 2 (svotrace.comp:444) */
   uint32_t mirror_mask; /* bit v set: material v reflects specularly (dormant svotrace.comp:500-504) */
   int32_t spp;          /* samples per pixel (dormant SAMPLES loop, svotrace.comp:668-670); live value 1 */
+  int32_t progressive;  /* cross-frame accumulation (dormant, commented out at svotrace.comp:712-719); live value 0.
+                           When set, `rgba` is read as the previous frame's image before it is overwritten. */
 } svo_oracle_params;
 
 typedef struct svo_oracle_stats {
@@ -625,6 +633,16 @@ int svo_oracle_render_beam(const uint8_t *pool, uint64_t pool_len, const svo_ora
       if (dword0 == 0) debugColor = v3(1.0f, 0.0f, 0.0f);
       if (px < 10 && py < 10) fin = debugColor;
       size_t o = (size_t)py * (size_t)W + (size_t)px;
+      if (prm->progressive && rgba && prm->frame_number > 1) { /* :712-719, pinned by tests/golden/accum_golden.npz */
+        /* imageLoad of an rgba8 image: unorm8 -> float */
+        vec3 last = v3(UNORM8_TO_FLOAT(rgba[o * 4 + 0]), UNORM8_TO_FLOAT(rgba[o * 4 + 1]), UNORM8_TO_FLOAT(rgba[o * 4 + 2]));
+        if (prm->frame_number < MAX_FRAME_ITER) {
+          const float fn = (float)prm->frame_number, fd = (float)(prm->frame_number + 1);
+          fin = v3(PROG_DIV(fn * last.x + fin.x, fd), PROG_DIV(fn * last.y + fin.y, fd), PROG_DIV(fn * last.z + fin.z, fd));
+        } else {
+          fin = last;
+        }
+      }
       if (rgba) {
         rgba[o * 4 + 0] = unorm8(fin.x);
         rgba[o * 4 + 1] = unorm8(fin.y);

@@ -22,6 +22,26 @@ __device__ __forceinline__ float beam_start(const Frame &f, int px, int py) {
   return f.use_beam ? f.beam[(size_t)(py >> 2) * (size_t)f.beam_w + (size_t)(px >> 2)] : 0.0f;
 }
 
+// What main() does with a pixel's colour before imageStore (svotrace.comp:696-726): the debug square, then -- when the
+// dormant cross-frame accumulation (:712-719) is switched on -- the running mean with the image the previous frame left
+// in the colour buffer: (frameNumber * last + colour) / (frameNumber + 1), frozen from MAX_FRAME_ITER = 100 on.
+// imageLoad of rgba8 = byte * (1/255); true division (both pinned by tests/golden/accum_golden.npz).
+__device__ __forceinline__ uint32_t final_rgba8(const Frame &f, int px, int py, V3 col, const uint32_t *dst) {
+  if (px < 10 && py < 10) col = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
+  if (f.progressive && f.frame_number > 1) {
+    const uint32_t last = *dst;
+    const V3 lc = mk((float)(last & 0xffu) * (1.0f / 255.0f), (float)((last >> 8) & 0xffu) * (1.0f / 255.0f),
+                     (float)((last >> 16) & 0xffu) * (1.0f / 255.0f));
+    if (f.frame_number < 100) {
+      const float fn = (float)f.frame_number, fd = (float)(f.frame_number + 1);
+      col = mk((fn * lc.x + col.x) / fd, (fn * lc.y + col.y) / fd, (fn * lc.z + col.z) / fd);
+    } else {
+      col = lc;
+    }
+  }
+  return unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
+}
+
 __device__ __forceinline__ V3 sky_colour(V3 d) {
   return mk(0.6725f - d.y * 0.4f, 0.8784f - d.y * 0.4f, 1.0f - d.y * 0.25f);
 }
@@ -160,9 +180,8 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
 
 __device__ __forceinline__ void store_pixel(const Frame &f, int px, int py, int oy, V3 fin, float depth,
                                             const PathState &ps, uint32_t *color, float *depthbuf, uint4 *hits) {
-  if (px < 10 && py < 10) fin = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
   const size_t o = (size_t)oy * (size_t)f.width + (size_t)px;
-  color[o] = unorm8(fin.x) | (unorm8(fin.y) << 8) | (unorm8(fin.z) << 16) | 0xff000000u;
+  color[o] = final_rgba8(f, px, py, fin, color + o);
   depthbuf[o] = depth;
   if (f.write_hits) {
     uint4 h;

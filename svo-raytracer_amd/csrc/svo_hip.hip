@@ -34,7 +34,7 @@ struct svo_ctx {
   int width = 0, height = 0, y0 = 0, y1 = 0;
   bool rows_set = false;
   int row_step = 1, out_y0 = 0, n_tile_rows = -1;  // stripe mode (svo_set_stripes); n_tile_rows < 0 = band mode
-  int frame_number = 2, render_mode = 2, buffer_end = 0, use_beam = 0, bounces = 2, spp = 1;
+  int frame_number = 2, render_mode = 2, buffer_end = 0, use_beam = 0, bounces = 2, spp = 1, progressive = 0;
   uint32_t mirror_mask = 0;
   int pipeline = 0;
   int write_hits = 1;
@@ -359,6 +359,12 @@ int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_sixteenths)
   return SVO_OK;
 }
 
+int svo_set_progressive(svo_ctx *c, int enabled) {
+  if (!c) return SVO_E_INVALID;
+  c->progressive = enabled ? 1 : 0;
+  return SVO_OK;
+}
+
 int svo_set_hit_records(svo_ctx *c, int enabled) {
   if (!c) return SVO_E_INVALID;
   c->write_hits = enabled ? 1 : 0;
@@ -398,6 +404,7 @@ static int make_frame(svo_ctx *c, Frame &f) {
   f.ntiles = f.tiles_x * f.tiles_y;
   f.write_hits = (c->write_hits && c->d_hits) ? 1 : 0;
   f.use_beam = 0; f.beam_w = 0; f.beam = nullptr;
+  f.progressive = c->progressive;
   if (!c->external_outputs && c->n_tile_rows > 0) {
     // packed stripes land at output rows out_y0 + 8 j + ly: they must stay inside the library's W x H images
     // (caller-owned gather buffers are the caller's to size, see svo_bind_outputs)

@@ -22,6 +22,9 @@ struct Frame {
   // beam pre-pass (useBeamOptimization, Main.java:257-283): start distance per 4x4 pixel block, or off
   int32_t use_beam, beam_w;
   const float *beam;
+  // cross-frame accumulation (commented out in the reference, svotrace.comp:712-719): blend with the image the
+  // previous frame left in the colour buffer
+  int32_t progressive;
 };
 
 // device-side counters of a counted frame

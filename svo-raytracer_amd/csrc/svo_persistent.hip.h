@@ -61,10 +61,10 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
   asm volatile("" ::"v"(col.x), "v"(col.y), "v"(col.z), "v"(depth), "v"(pix));
   return;
 #endif
-  if (a.f.spp <= 1) {
+  if (a.f.spp <= 1 && !a.f.progressive) {   // the live shader's case: straight to rgba8
     if (px < 10 && py < 10) col = a.f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
     a.color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
-  } else {
+  } else {   // several samples and / or cross-frame accumulation: float sums, finished by persist_resolve_kernel
     float *fx = a.facc + pix, *fy = a.facc + a.npix + pix, *fz = a.facc + 2 * a.npix + pix;
     if (a.sample == 0) { *fx = 0.0f + col.x; *fy = 0.0f + col.y; *fz = 0.0f + col.z; }
     else { *fx = *fx + col.x; *fy = *fy + col.y; *fz = *fz + col.z; }
@@ -355,9 +355,8 @@ __global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t 
   if (x >= f.width || y >= f.y1 || y >= f.height) return;
   const size_t pix = (size_t)frame_oy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7) * f.width + x;
   const float inv = 1.0f / (float)f.spp;
-  V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
-  if (x < 10 && y < 10) col = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
-  color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
+  const V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
+  color[pix] = final_rgba8(f, x, y, col, color + pix);
 }
 
 // `out_npix` = elements of the output images: W*H, or more when packed stripes overhang the frame (caller-owned
@@ -388,9 +387,10 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     b.blocks = b.cus * per_cu;
   }
   const int spp = f.spp < 1 ? 1 : f.spp;
+  const bool resolve = spp > 1 || f.progressive;   // colours go through the float planes and the resolve kernel
   float *facc = nullptr;
   int fset = 0;
-  if (spp > 1) {
+  if (resolve) {
     if (b.npix < npix) {   // grow: nothing may still be summing into the old planes
       if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
       for (int i = 0; i < kFaccSets; i++) {
@@ -430,7 +430,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     if ((e = hipEventRecord(b.head_done[hset], stream)) != hipSuccess) return (int)e;
     b.head_used[hset] = true;
   }
-  if (spp > 1) {
+  if (resolve) {
     dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8));
     hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, facc, b.npix, color);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64, SVO_TRACE_WAVES_PER_SIMD) void wf_trace_kernel(
 // ---------------------------------------------------------------------------------------------------
 // shade: one thread per traced ray
 __device__ __forceinline__ void wf_emit(const WfArgs &a, uint32_t pix, int px, int py, V3 col, bool set_depth, float depth) {
-  if (a.f.spp <= 1) {
+  if (a.f.spp <= 1 && !a.f.progressive) {
     if (px < 10 && py < 10) col = a.f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
     a.color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
   } else {
@@ -385,9 +385,8 @@ __global__ void resolve_kernel(const Frame f, const float *facc, size_t npix, ui
   if (x >= f.width || y >= f.y1 || y >= f.height) return;
   const size_t pix = (size_t)frame_oy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7) * f.width + x;
   const float inv = 1.0f / (float)f.spp;
-  V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
-  if (x < 10 && y < 10) col = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
-  color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
+  const V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
+  color[pix] = final_rgba8(f, x, y, col, color + pix);
 }
 
 inline int wavefront_prepare(WavefrontBuffers &b, const Frame &f, size_t out_npix) {
@@ -473,7 +472,7 @@ inline int wavefront_launch(WavefrontBuffers &b, const uint8_t *pool, const Fram
       if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     }
   }
-  if (spp > 1) {
+  if (spp > 1 || f.progressive) {
     dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8));
     hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, stream, f, S.facc, b.npix, color);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
