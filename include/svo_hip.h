@@ -105,6 +105,11 @@ int svo_pool_device_ptr(svo_ctx *ctx, void **dptr, uint64_t *nbytes);
  * svo_pool_upload; read it with svo_pool_download); *out_nbytes = its size.  SVO_E_TOOLARGE if it would not fit
  * signed 32-bit child pointers. */
 int svo_build_from_heightmap(svo_ctx *ctx, const uint16_t *height, const uint8_t *material, int n, uint64_t *out_nbytes);
+/* replaces OctreeThread.run / Octree.constructInnerOctree (OctreeThread.java:20-23, Octree.java:511-670) for a dense
+ * chunk of voxels, whatever produced them (the reference fills chunks from height maps or from 3-D noise,
+ * chunkgen*.comp): voxels[x | y << log2 n | z << 2 log2 n] (Octree.java:110-112), 0 = empty, n a power of two in
+ * 2..1024 (one chunk).  The result becomes the context's pool, as above. */
+int svo_build_from_voxels(svo_ctx *ctx, const uint8_t *voxels, int n, uint64_t *out_nbytes);
 
 /* ---- per-frame state (the shader's uniforms) ------------------------------------- */
 /* replaces glUniform3fv(8,pos), (1..4, l1,l2,r1,r2) (Main.java:269-273); values as

@@ -33,6 +33,7 @@ constexpr int kChunk = 1024;   // Octree.java:39
 constexpr int kTask = 512;     // OctreeThread.java:22
 enum : uint32_t { T_INTERIOR = 0, T_SURFACE = 1, T_SUBDIV = 2, T_NONSURFACE = 3 };   // Octree.java:589-599
 
+// voxel source 1: a height map and a material map (the reference's world generator, chunkgen-heightmap.comp)
 struct Maps {
   const uint16_t *h;     // N*N heights, index z*N + x: the column is solid for y <= h
   const uint8_t *mat;    // N*N surface materials (the top five layers of a column)
@@ -41,6 +42,21 @@ struct Maps {
   const int16_t *pdeep[12];   // min over the cell of the deepest y up to which a column is uniformly value 1:
                               // h when its surface material is 1 as well, else h - 5 (below the material band)
   int n, chunk;
+  __device__ __forceinline__ bool empty_at(int x, int y, int z) const { return y > (int)h[(size_t)z * n + x]; }
+};
+
+// voxel source 2: a dense chunk of voxels, the input of Octree.constructInnerOctree itself (index x | y << shift |
+// z << 2 shift, Octree.java:110-112), with a summary per cube of 2, 4, ... n voxels: whether all its voxels are equal,
+// and its first non-empty voxel in the reference's z, y, x scan order (position key z << 20 | y << 10 | x, and value)
+struct Grid {
+  const uint8_t *vox;
+  const uint32_t *fpos[11];   // level k: cubes of 2^k; first non-empty voxel's key, 0xffffffff if the cube is empty
+  const uint16_t *fval[11];   // its value | 0x100 if the cube is homogeneous
+  int n, shift, chunk;
+  __device__ __forceinline__ uint32_t at(int x, int y, int z) const {
+    return vox[(size_t)x | ((size_t)y << shift) | ((size_t)z << (2 * shift))];
+  }
+  __device__ __forceinline__ bool empty_at(int x, int y, int z) const { return at(x, y, z) == 0u; }
 };
 
 // one level of the tree: the nodes that own a block of 8 children, in depth-first order
@@ -64,7 +80,8 @@ __device__ __forceinline__ uint32_t voxel_at(const Maps &m, int x, int y, int z)
   if (h - y <= 4) return m.mat[(size_t)z * m.n + x];
   return 1u;
 }
-__device__ __forceinline__ bool usable(const Maps &m, int g, int c) {   // inside the world and inside c's chunk
+template <class Src>
+__device__ __forceinline__ bool usable(const Src &m, int g, int c) {   // inside the world and inside c's chunk
   const int o = (c / m.chunk) * m.chunk;
   return g >= 0 && g < m.n && g >= o && g < o + m.chunk;
 }
@@ -114,18 +131,28 @@ __device__ __forceinline__ int classify(const Maps &m, int cx, int cy, int cz, i
   return val ? 1 : 0;
 }
 
+__device__ __forceinline__ int classify(const Grid &m, int cx, int cy, int cz, int cs, uint32_t &value) {
+  if (cs == 1) { value = m.at(cx, cy, cz); return value ? 1 : 0; }
+  const int k = 31 - __builtin_clz((unsigned)cs);
+  const size_t w = (size_t)(m.n >> k);
+  const uint32_t fv = m.fval[k][(((size_t)(cz >> k)) * w + (size_t)(cy >> k)) * w + (size_t)(cx >> k)];
+  value = fv & 0xffu;
+  if (fv & 0x100u) return value ? 1 : 0;
+  return 2;
+}
+
 // genSurfaceNormal (Octree.java:620-649): offsets to the empty usable 26-neighbours, summed, halved toward zero
-__device__ __forceinline__ bool surface_normal(const Maps &m, int cx, int cy, int cz, uint32_t &packed) {
+template <class Src>
+__device__ __forceinline__ bool surface_normal(const Src &m, int cx, int cy, int cz, uint32_t &packed) {
   bool exposed = false;
   int nx = 0, ny = 0, nz = 0;
   for (int i = cx - 1; i <= cx + 1; i++) {
     if (!usable(m, i, cx)) continue;
     for (int k = cz - 1; k <= cz + 1; k++) {
       if (!usable(m, k, cz)) continue;
-      const int h = m.h[(size_t)k * m.n + i];
       for (int j = cy - 1; j <= cy + 1; j++) {
         if (!usable(m, j, cy)) continue;
-        if (j > h) { exposed = true; nx += i - cx; ny += j - cy; nz += k - cz; }
+        if (m.empty_at(i, j, k)) { exposed = true; nx += i - cx; ny += j - cy; nz += k - cz; }
       }
     }
   }
@@ -134,7 +161,8 @@ __device__ __forceinline__ bool surface_normal(const Maps &m, int cx, int cy, in
 }
 
 // checkBigNodeExposed (Octree.java:651-670): only coordinates {c - 1, c + cs, c + cs + 1} are looked at on every axis
-__device__ __forceinline__ bool big_node_exposed(const Maps &m, int cx, int cy, int cz, int cs) {
+template <class Src>
+__device__ __forceinline__ bool big_node_exposed(const Src &m, int cx, int cy, int cz, int cs) {
   const int dx[3] = {-1, cs, cs + 1};
   for (int a = 0; a < 3; a++) {
     const int x = cx + dx[a];
@@ -142,11 +170,10 @@ __device__ __forceinline__ bool big_node_exposed(const Maps &m, int cx, int cy, 
     for (int c = 0; c < 3; c++) {
       const int z = cz + dx[c];
       if (!usable(m, z, cz)) continue;
-      const int h = m.h[(size_t)z * m.n + x];
       for (int b = 0; b < 3; b++) {
         const int y = cy + dx[b];
         if (!usable(m, y, cy)) continue;
-        if (y > h) return true;
+        if (m.empty_at(x, y, z)) return true;
       }
     }
   }
@@ -200,8 +227,8 @@ __global__ void pyramid_up_kernel(const uint16_t *imin, const uint16_t *imax, co
 
 // ---- one level: classify the 8 children of every node ---------------------------------------------------------
 // thread = (node, child octant); the 8 lanes of a node sit in one wave
-template <bool kForced>
-__global__ __launch_bounds__(256) void classify_kernel(const Maps m, const Level lv) {
+template <class Src, bool kForced>
+__global__ __launch_bounds__(256) void classify_kernel(const Src m, const Level lv) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t i = t >> 3, n = t & 7u;
   const bool live = i < lv.count;
@@ -428,6 +455,9 @@ struct Result {
 
 // d_h / d_mat: device copies of the maps.  Returns hipSuccess, or hipErrorInvalidValue for a bad size,
 // hipErrorOutOfMemory / others from the runtime; *too_large is set when the pool would reach 2^31 bytes.
+template <class Src>
+inline hipError_t build_levels(Builder &B, const Src &m, int n, uint64_t pad, hipStream_t stream, Result &res, bool *too_large);
+
 inline hipError_t build_pool(const uint16_t *d_h, const uint8_t *d_mat, int n, uint64_t pad, hipStream_t stream, Result &res,
                              bool *too_large) {
   *too_large = false;
@@ -451,7 +481,74 @@ inline hipError_t build_pool(const uint16_t *d_h, const uint8_t *d_mat, int n, u
                          m.pdeep[l - 1], w, mn, mx, dp);
     m.pmin[l] = mn; m.pmax[l] = mx; m.pdeep[l] = dp;
   }
+  return build_levels(B, m, n, pad, stream, res, too_large);
+}
 
+// ---- voxel source 2: summaries of a dense chunk ------------------------------------------------------------------
+// level 1 from the voxels: one thread per cube of 2
+__global__ void grid_base_kernel(const uint8_t *vox, int n, int shift, uint32_t *fpos, uint16_t *fval) {
+  const size_t w = (size_t)(n >> 1);
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= w * w * w) return;
+  const int cx = (int)(c % w) * 2, cy = (int)((c / w) % w) * 2, cz = (int)(c / (w * w)) * 2;
+  uint32_t first_key = 0xffffffffu, first_val = 0u;
+  const uint32_t v0 = vox[(size_t)cx | ((size_t)cy << shift) | ((size_t)cz << (2 * shift))];
+  bool same = true;
+  for (int z = cz; z < cz + 2; z++)        // the reference's scan order: z, then y, then x (Octree.java:535-537)
+    for (int y = cy; y < cy + 2; y++)
+      for (int x = cx; x < cx + 2; x++) {
+        const uint32_t v = vox[(size_t)x | ((size_t)y << shift) | ((size_t)z << (2 * shift))];
+        same = same && v == v0;
+        if (v != 0u && first_key == 0xffffffffu) { first_key = ((uint32_t)z << 20) | ((uint32_t)y << 10) | (uint32_t)x; first_val = v; }
+      }
+  fpos[c] = first_key;
+  fval[c] = (uint16_t)(first_val | (same ? 0x100u : 0u));
+}
+// level k from level k - 1: a cube is homogeneous when its 8 parts are and agree; its first non-empty voxel is the one
+// with the smallest (z, y, x) among its parts' first voxels
+__global__ void grid_up_kernel(const uint32_t *ipos, const uint16_t *ival, int w, uint32_t *fpos, uint16_t *fval) {
+  const size_t W = (size_t)w, c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= W * W * W) return;
+  const size_t cx = c % W, cy = (c / W) % W, cz = c / (W * W), w2 = W * 2;
+  uint32_t best = 0xffffffffu, bval = 0u, v0 = 0u;
+  bool same = true;
+  for (int i = 0; i < 8; i++) {
+    const size_t j = ((cz * 2 + (size_t)((i >> 2) & 1)) * w2 + (cy * 2 + (size_t)((i >> 1) & 1))) * w2 + (cx * 2 + (size_t)(i & 1));
+    const uint32_t pk = ipos[j], pv = ival[j];
+    if (i == 0) v0 = pv;
+    same = same && (pv & 0x100u) != 0u && pv == v0;
+    if (pk < best) { best = pk; bval = pv & 0xffu; }
+  }
+  fpos[c] = best;
+  fval[c] = (uint16_t)(bval | (same ? 0x100u : 0u));
+}
+
+// d_vox: device copy of an n^3 chunk (n a power of two, 2..1024), indexed x | y << log2 n | z << 2 log2 n.
+inline hipError_t build_pool_from_voxels(const uint8_t *d_vox, int n, uint64_t pad, hipStream_t stream, Result &res, bool *too_large) {
+  *too_large = false;
+  if (n < 2 || n > kChunk || (n & (n - 1))) return hipErrorInvalidValue;
+  Builder B;
+  B.stream = stream;
+  Grid g;
+  g.vox = d_vox; g.n = n; g.chunk = n; g.shift = 0;
+  while ((1 << g.shift) < n) g.shift++;
+  for (int k = 0; k < 11; k++) { g.fpos[k] = nullptr; g.fval[k] = nullptr; }
+  for (int k = 1; k <= g.shift; k++) {
+    const size_t w = (size_t)(n >> k), cells = w * w * w;
+    uint32_t *fp = B.alloc<uint32_t>(cells);
+    uint16_t *fv = B.alloc<uint16_t>(cells);
+    if (!fp || !fv) { B.release(); return B.err; }
+    const unsigned grid = (unsigned)((cells + 255) / 256);
+    if (k == 1) hipLaunchKernelGGL(grid_base_kernel, dim3(grid), dim3(256), 0, stream, d_vox, n, g.shift, fp, fv);
+    else hipLaunchKernelGGL(grid_up_kernel, dim3(grid), dim3(256), 0, stream, g.fpos[k - 1], g.fval[k - 1], (int)w, fp, fv);
+    g.fpos[k] = fp; g.fval[k] = fv;
+  }
+  return build_levels(B, g, n, pad, stream, res, too_large);
+}
+
+// Levels, offsets and emission for any voxel source (the source's summaries are already built; B owns the scratch).
+template <class Src>
+inline hipError_t build_levels(Builder &B, const Src &m, int n, uint64_t pad, hipStream_t stream, Result &res, bool *too_large) {
   // the pool's prefix and the first level: the chunk nodes (or the root itself for worlds of one 512^3 task)
   std::vector<uint8_t> pre = {1, 0, 0, 0, 0, 0, 0};   // createDummyHead / the root: interior, value 1
   std::vector<uint32_t> chunk_nodes;
@@ -487,8 +584,8 @@ inline hipError_t build_pool(const uint16_t *d_h, const uint8_t *d_mat, int n, u
     if (L.size == 2) L.normals = B.alloc<uint16_t>(c * 8);
     if (!B.ok()) break;
     const unsigned grid = (unsigned)((c * 8 + 255) / 256);
-    if (chunked && d == 0) hipLaunchKernelGGL(classify_kernel<true>, dim3(grid), dim3(256), 0, stream, m, L);
-    else hipLaunchKernelGGL(classify_kernel<false>, dim3(grid), dim3(256), 0, stream, m, L);
+    if (chunked && d == 0) hipLaunchKernelGGL((classify_kernel<Src, true>), dim3(grid), dim3(256), 0, stream, m, L);
+    else hipLaunchKernelGGL((classify_kernel<Src, false>), dim3(grid), dim3(256), 0, stream, m, L);
     uint32_t total = 0;
     B.exclusive_scan<uint8_t, true>(L.expmask, L.first, (uint32_t)c, &total);
     if (!B.ok() || total == 0 || L.size == 2) break;

@@ -275,6 +275,30 @@ int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *
   return refresh_dword0(c);
 }
 
+int svo_build_from_voxels(svo_ctx *c, const uint8_t *voxels, int n, uint64_t *out_nbytes) {
+  if (!c || !voxels) return fail(c, SVO_E_INVALID, "svo_build_from_voxels: null grid");
+  if (n < 2 || n > 1024 || (n & (n - 1))) return fail(c, SVO_E_INVALID, "svo_build_from_voxels: n must be a power of two in 2..1024");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  const size_t cells = (size_t)n * (size_t)n * (size_t)n;
+  uint8_t *d_v = nullptr;
+  hipError_t e = hipMalloc((void **)&d_v, cells);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_v, voxels, cells, hipMemcpyHostToDevice, c->stream);
+  build::Result r;
+  bool too_large = false;
+  if (e == hipSuccess) e = build::build_pool_from_voxels(d_v, n, kPad, c->stream, r, &too_large);
+  if (d_v) (void)hipFree(d_v);
+  if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_build_from_voxels: ") + hipGetErrorString(e));
+  if (too_large) {
+    if (out_nbytes) *out_nbytes = r.len;
+    return fail(c, SVO_E_TOOLARGE, "pool must stay below 2^31 bytes");
+  }
+  if (c->d_pool) (void)hipFree(c->d_pool);
+  c->d_pool = r.pool; c->pool_len = r.len; c->pool_cap = r.cap;
+  if (out_nbytes) *out_nbytes = r.len;
+  return refresh_dword0(c);
+}
+
 // ---------------------------------------------------------------- frame state
 int svo_set_camera(svo_ctx *c, const float pos[3], const float l1[3], const float l2[3], const float r1[3],
                    const float r2[3]) {

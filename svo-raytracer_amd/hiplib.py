@@ -14,7 +14,7 @@ HIT_DTYPE = np.dtype([("pointer", "<u4"), ("raw_normal", "<u2"), ("value", "u1")
 
 EXPORTS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
-    "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
+    "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_build_from_voxels", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel", "svo_read_beam",
     "svo_output_device_ptrs",
@@ -59,6 +59,7 @@ def lib(path=None):
         L.svo_pool_reserve.argtypes = [vp, u64]
         L.svo_pool_upload_device.argtypes = [vp, vp, u64]
         L.svo_build_from_heightmap.argtypes = [vp, vp, vp, ci, ctypes.POINTER(u64)]
+        L.svo_build_from_voxels.argtypes = [vp, vp, ci, ctypes.POINTER(u64)]
         L.svo_bind_outputs.argtypes = [vp, vp, vp, vp]
         L.svo_pool_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
         L.svo_set_camera.argtypes = [vp, fp, fp, fp, fp, fp]
@@ -147,6 +148,15 @@ class HipContext:
         assert height.shape == (n, n) and material.shape == (n, n)
         nb = ctypes.c_uint64()
         self._chk(self._L.svo_build_from_heightmap(self._h, height.ctypes.data, material.ctypes.data, n, ctypes.byref(nb)))
+        return int(nb.value)
+
+    def build_from_voxels(self, grid):
+        """GPU builder over a dense chunk grid[z, y, x] (svo_build_from_voxels); returns the size of the new pool."""
+        grid = np.ascontiguousarray(grid, dtype=np.uint8)
+        n = grid.shape[0]
+        assert grid.shape == (n, n, n)
+        nb = ctypes.c_uint64()
+        self._chk(self._L.svo_build_from_voxels(self._h, grid.ctypes.data, n, ctypes.byref(nb)))
         return int(nb.value)
 
     def bind_outputs(self, color_ptr, depth_ptr, hits_ptr=None):

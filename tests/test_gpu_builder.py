@@ -20,12 +20,14 @@ def ctx():
 
 
 def dense_grid(height, material):
-    """chunkgen-heightmap.comp:16-28 over the whole world: grid[z, y, x]"""
+    """chunkgen-heightmap.comp:16-28 over the whole world: grid[z, y, x] (slab by slab: 1 GiB at 1024^3, no big temporaries)"""
     n = height.shape[0]
-    y = np.arange(n, dtype=np.int32)[None, :, None]
-    h = height.astype(np.int32)[:, None, :]
-    m = material[:, None, :]
-    return np.where(y > h, 0, np.where(h - y <= 4, m, 1)).astype(np.uint8)
+    g = np.empty((n, n, n), dtype=np.uint8)
+    y = np.arange(n, dtype=np.int32)[:, None]
+    for z in range(n):
+        h = height[z].astype(np.int32)[None, :]
+        g[z] = np.where(y > h, 0, np.where(h - y <= 4, material[z][None, :], 1))
+    return g
 
 
 def restated_pool(height, material):
@@ -122,3 +124,76 @@ def test_builder_rejects_bad_input(ctx):
     m[3, 4] = 0
     with pytest.raises(hiplib.SvoError):
         ctx.build_from_heightmap(h, m)            # material 0 = the empty voxel
+
+
+# ---- dense voxel chunks: Octree.constructInnerOctree's own input ----------------------------------------------------
+
+def _restated_from_grid(grid):
+    from svo_raytracer_amd import hostlib
+    from oracle import octree as restated
+    n = grid.shape[0]
+    o = hostlib.Octree(max(4096, n * n * n // 128))
+    restated.constructInnerOctree(o, grid, int(np.log2(n)))
+    return o.getByteBuffer()
+
+
+def _cave_grid(n, seed):
+    """Things no height map produces: overhangs, floating islands, tunnels, hollow shells, several materials, solid and
+    empty cubes of every size at every alignment."""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    g = np.zeros((n, n, n), dtype=np.uint8)
+    g[y < n // 3] = 1                                                   # ground slab
+    for _ in range(6):                                                  # spheres: islands (solid) and caves (carved)
+        c = rng.integers(0, n, size=3)
+        r = int(rng.integers(max(2, n // 16), max(3, n // 4)))
+        inside = (x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2 <= r * r
+        g[inside] = int(rng.integers(0, 4))
+    a = int(rng.integers(0, n // 2))
+    g[a:a + n // 4, :, a:a + 2] = 3                                     # a thin wall
+    g[:, n // 2:n // 2 + 1, :] = np.where(rng.random((n, 1, n)) < 0.3, 2, g[:, n // 2:n // 2 + 1, :])   # dust layer
+    b = n // 8 * 3
+    g[b:b + n // 8, b:b + n // 8, b:b + n // 8] = 2                      # an aligned solid cube of one material
+    g[0:n // 4, n - n // 4:n, 0:n // 4] = 0                             # an aligned empty cube
+    return g
+
+
+@pytest.mark.parametrize("n,seed", [(2, 0), (4, 1), (8, 2), (16, 3), (32, 4), (64, 5), (64, 6), (128, 7)])
+def test_voxel_chunks_equal_restated_constructInnerOctree(ctx, n, seed):
+    import svo_raytracer_amd.scene as scene
+    g = _cave_grid(n, seed) if n >= 8 else np.random.default_rng(seed).integers(0, 3, size=(n, n, n)).astype(np.uint8)
+    nbytes = ctx.build_from_voxels(g)
+    got = ctx.pool_download(nbytes)
+    ref = _restated_from_grid(g)
+    assert got.size == ref.size and (got == ref).all()
+    assert scene.validate_pool(got)[0] == 0
+
+
+@pytest.mark.parametrize("n", [64, 256, 512])
+def test_voxel_chunk_of_the_terrain_equals_the_heightmap_builder(ctx, n):
+    """The same world through both GPU builders (and the CPU generator): dense voxels of the maps vs the maps."""
+    import svo_raytracer_amd.scene as scene
+    h, m = scene.scene_maps(n)
+    nb = ctx.build_from_voxels(dense_grid(h, m))
+    a = ctx.pool_download(nb)
+    ref, _ = scene.build_scene(n)
+    assert a.size == ref.size and (a == ref).all()
+
+
+def test_full_chunk_1024_from_voxels(ctx):
+    """A whole 1024^3 chunk (1 GiB of voxels, the reference's unit of world generation): eight forced 512^3 tasks under
+    the chunk node, neighbours outside the chunk ignored -- the bytes of the CPU generator and of the heightmap builder."""
+    import svo_raytracer_amd.scene as scene
+    n = 1024
+    h, m = scene.scene_maps(n)
+    t0 = time.time()
+    g = dense_grid(h, m)
+    t_grid = time.time() - t0
+    t0 = time.time()
+    nb = ctx.build_from_voxels(g)
+    t_build = time.time() - t0
+    del g
+    got = ctx.pool_download(nb)
+    ref, _ = scene.build_scene(n)
+    print("1024^3 voxels: numpy grid %.1f s, GPU build %.2f s (incl. 1 GiB upload), pool %d bytes" % (t_grid, t_build, nb))
+    assert got.size == ref.size and (got == ref).all()
