@@ -57,6 +57,11 @@ jint Java_src_engine_HipRenderer_nReadBeam(void *env, void *cls, jlong ctx, jlon
  * materials; returns the new pool's size in bytes (what Octree.memOffset would be), or a negative status */
 jlong Java_src_engine_HipRenderer_nBuildFromHeightmap(void *env, void *cls, jlong ctx, jlong height_addr,
                                                       jlong material_addr, jint n);
+/* OctreeThread.run / constructInnerOctree over a dense chunk (OctreeThread.java:20-23): address of n^3 voxel bytes,
+ * the layout of the reference's voxelBuffer (x | y << log2 n | z << 2 log2 n); returns the pool size or a negative status */
+jlong Java_src_engine_HipRenderer_nBuildFromVoxels(void *env, void *cls, jlong ctx, jlong voxels_addr, jint n);
+/* the commented-out cross-frame accumulation of svotrace.comp:712-719 */
+jint Java_src_engine_HipRenderer_nSetProgressive(void *env, void *cls, jlong ctx, jint enabled);
 
 #ifdef __cplusplus
 }

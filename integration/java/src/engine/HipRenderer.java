@@ -173,6 +173,19 @@ public class HipRenderer {
     return r;
   }
 
+  /** OctreeThread / constructInnerOctree over one dense chunk (the reference's voxelBuffer layout), on the GPU. */
+  public long buildFromVoxels(ByteBuffer voxels, int n) {
+    long r = nBuildFromVoxels(ctx, MemoryUtil.memAddress(voxels), n);
+    if (r < 0)
+      printGLErrors();
+    return r;
+  }
+
+  /** The commented-out cross-frame accumulation of svotrace.comp:712-719 (default off = the live shader). */
+  public void setProgressive(boolean on) {
+    check(nSetProgressive(ctx, on ? 1 : 0));
+  }
+
   /** Dormant shader features (svotrace.comp:444, 500-504, 668-670); defaults = live behaviour. */
   public void setPathOptions(int bounces, int mirrorMask, int spp) {
     this.bounces = bounces;
@@ -200,6 +213,8 @@ public class HipRenderer {
   private static native int nReadColor(long ctx, long addr);
   private static native int nReadDepth(long ctx, long addr);
   private static native int nReadHits(long ctx, long addr);
+  private static native long nBuildFromVoxels(long ctx, long voxelsAddr, int n);
+  private static native int nSetProgressive(long ctx, int enabled);
   private static native int nReadBeam(long ctx, long addr);
   private static native long nBuildFromHeightmap(long ctx, long heightAddr, long materialAddr, int n);
   private static native int nReadPixel(long ctx, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);

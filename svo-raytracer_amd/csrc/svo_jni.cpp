@@ -62,5 +62,13 @@ jlong Java_src_engine_HipRenderer_nBuildFromHeightmap(void *, void *, jlong ctx,
                                           (const uint8_t *)(intptr_t)material_addr, n, &nbytes);
   return rc == SVO_OK ? (jlong)nbytes : (jlong)rc;   // the pool's size (memOffset), or a negative status
 }
+jlong Java_src_engine_HipRenderer_nBuildFromVoxels(void *, void *, jlong ctx, jlong voxels_addr, jint n) {
+  uint64_t nbytes = 0;
+  const int rc = svo_build_from_voxels((svo_ctx *)(intptr_t)ctx, (const uint8_t *)(intptr_t)voxels_addr, n, &nbytes);
+  return rc == SVO_OK ? (jlong)nbytes : (jlong)rc;
+}
+jint Java_src_engine_HipRenderer_nSetProgressive(void *, void *, jlong ctx, jint enabled) {
+  return svo_set_progressive((svo_ctx *)(intptr_t)ctx, enabled);
+}
 
 }  // extern "C"

@@ -61,6 +61,8 @@ def test_jni_shim_called_with_jni_typed_arguments(ctx):
     nReadPixel = fn("nReadPixel", jint, jlong, jint, jint, jlong, jlong, jlong)
     nReadBeam = fn("nReadBeam", jint, jlong, jlong)
     nBuildFromHeightmap = fn("nBuildFromHeightmap", jlong, jlong, jlong, jlong, jint)
+    nBuildFromVoxels = fn("nBuildFromVoxels", jlong, jlong, jlong, jint)
+    nSetProgressive = fn("nSetProgressive", jint, jlong, jint)
 
     pool, _ = scene.build_scene(128)
     cam = np.asarray(CAMERAS["K1"], dtype=np.float32)
@@ -118,6 +120,15 @@ def test_jni_shim_called_with_jni_typed_arguments(ctx):
         want3 = ctx.render(pool, w, h, cam, 3, 0, use_beam=1)
         assert np.array_equal(beam.view(np.uint32), ctx.read_beam().view(np.uint32))
         assert nReadColor(j, rgba.ctypes.data) == 0 and (rgba == want3["rgba"]).all()
+        small, _ = scene.build_scene(32)
+        hs, ms = scene.scene_maps(32)
+        yy = np.arange(32, dtype=np.int32)[None, :, None]
+        grid = np.where(yy > hs.astype(np.int32)[:, None, :], 0,
+                        np.where(hs.astype(np.int32)[:, None, :] - yy <= 4, ms[:, None, :], 1)).astype(np.uint8)
+        assert nBuildFromVoxels(j, grid.ctypes.data, 32) == small.size
+        back2 = np.zeros(small.size, dtype=np.uint8)
+        assert nPoolDownload(j, back2.ctypes.data, back2.size) == 0 and (back2 == small).all()
+        assert nSetProgressive(j, 1) == 0 and nSetProgressive(j, 0) == 0
     finally:
         assert nDestroy(j) == 0
 
