@@ -648,7 +648,7 @@ int svo_debug_heads(svo_ctx *c, void *out) {
   if (!c || !out || !c->pb.heads) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemcpy(out, c->pb.heads + (size_t)((c->pb.launches - 1) % kHeadSets) * kHeadWords + 8 * kHeadStride, 128, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out, c->pb.heads + (size_t)((c->pb.frames - 1) % kHeadSets) * kHeadWords + 8 * kHeadStride, 128, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
 #endif

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #endif
 }
 
-constexpr int kHeadSets = 8;   // counter sets: one per launch, reused round-robin
+constexpr int kHeadSets = 8;   // counter sets: one per frame in flight (its sample launches follow one another on one
+                               // stream and share it), reused round-robin
 constexpr int kFaccSets = 4;   // colour-sum buffers (spp > 1): one per frame, reused round-robin
 
 struct PersistBuffers {
@@ -389,6 +390,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   const int spp = f.spp < 1 ? 1 : f.spp;
   const bool resolve = spp > 1 || f.progressive;   // colours go through the float planes and the resolve kernel
   float *facc = nullptr;
+  const unsigned frame_no = b.frames++;
   int fset = 0;
   if (resolve) {
     if (b.npix < npix) {   // grow: nothing may still be summing into the old planes
@@ -401,7 +403,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
       }
       b.npix = npix;
     }
-    fset = (int)(b.frames++ % kFaccSets);
+    fset = (int)(frame_no % kFaccSets);
     facc = b.facc[fset];
     if (b.facc_used[fset] && (e = hipStreamWaitEvent(stream, b.facc_done[fset], 0)) != hipSuccess) return (int)e;
   }
@@ -411,12 +413,13 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.rows_per_band = (f.tiles_y + 7) / 8;
   a.thresh_num = b.thresh_num;
   const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
+  // a ring of counter sets: frames may be in flight on different streams at the same time.  A frame's sample launches
+  // are ordered by its stream, so they share the frame's set; only another frame's re-use waits (for the event)
+  const int hset = (int)(frame_no % kHeadSets);
+  a.heads = b.heads + (size_t)hset * kHeadWords;
+  if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
   for (int s = 0; s < spp; s++) {
-    // a ring of counter sets: frames may be in flight on different streams at the same time
-    a.reverse = SVO_SERPENTINE ? (int)(b.launches & 1u) : 0;
-    const int hset = (int)(b.launches++ % kHeadSets);
-    a.heads = b.heads + (size_t)hset * kHeadWords;
-    if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
+    a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;
     if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
     switch (f.render_mode) {
@@ -427,9 +430,9 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
       default: persist_launch_mode<4>(a, blocks, stream); break;
     }
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    if ((e = hipEventRecord(b.head_done[hset], stream)) != hipSuccess) return (int)e;
-    b.head_used[hset] = true;
   }
+  if ((e = hipEventRecord(b.head_done[hset], stream)) != hipSuccess) return (int)e;
+  b.head_used[hset] = true;
   if (resolve) {
     dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8));
     hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, facc, b.npix, color);
