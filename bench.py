@@ -22,6 +22,11 @@ depth in one message) are gathered to rank 0 over xGMI (one direct send per peer
 the next frames' traversal.  --scaling weak keeps 1920x1080 pixels per GPU instead (the frame grows
 to 1920 x 1080*N rows of the same view).
 
+Throughput configuration (all of it on the JSON line): --inflight 3 dispatches in flight on alternating streams, each
+dispatch a batch of --batch 4 consecutive frames (svo_set_batch: one persistent launch whose waves run from frame to
+frame, so the launch's tail is paid once per batch).  A step is still ONE frame: K steps = K frames, the last dispatch
+a partial batch if need be.  `--inflight 1 --batch 1` is the reference's own loop, one frame at a time.
+
 Presets: --config C2 | C3 (default, the metric) | C4 | C5 are BASELINE.json's configs.
 Also on the JSON line: roofline (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM, plus the
 instruction-issue figures that actually bind, from the committed PMC passes when they were taken on
@@ -44,6 +49,11 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 SIMDS = 1024            # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
 VALU_CYCLES = 2.5       # measured: a SIMD retires one wave64 VALU instruction per ~2.5 cycles (profiles/r01b_calib_valu.txt)
+
+# frames per dispatch when --batch is not given (the same for every number of GPUs, so that the scaling curve compares like
+# with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N
+# (tools/r02_batch_probe.sh, tools/r02_batch.sh: 1 GPU 4.38 -> 4.54 Grays/s; rank 0 of 8: 0.152 -> 0.106 ms per frame)
+DEFAULT_BATCH = {1: 4, 2: 4, 4: 4, 8: 4}
 
 PRESETS = {
     # name: size, width, height, mode, bounces (path segments), mirror mask, spp
@@ -74,11 +84,16 @@ def parse(argv=None):
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("SVO_BENCH_INFLIGHT", "3")),
                     help="frames in flight (streams x output buffers); the next frame fills the GPU while the "
                          "previous one drains its longest paths")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SVO_BENCH_BATCH", "0")),
+                    help="frames per dispatch (svo_set_batch): one persistent launch carries that many consecutive frames, so "
+                         "its tail is paid once per batch; 0 = default (see DEFAULT_BATCH)")
     ap.add_argument("--waves", type=int, default=-1, help="persistent waves per CU and frame (-1 = 10 with frames in flight, else fill)")
     ap.add_argument("--thresh", type=int, default=9, help="refill round threshold in sixteenths")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle sample time (0 = skip)")
     ap.add_argument("--hits", type=int, default=0, help="also store 16-byte hit records per pixel")
     ap.add_argument("--verify", type=int, default=1, help="check the ring's frames against the CPU oracle after timing")
+    ap.add_argument("--isolated", type=int, default=1, help="also time single frames with the GPU to themselves (kernel_ms_isolated); "
+                                                          "0 in PMC passes, so that every launch of the kernel is a timed-region launch")
     ap.add_argument("--beam", type=int, default=0, help="useBeamOptimization (coarse depth pre-pass, Main.java:257-266)")
     ap.add_argument("--as-rank", default=None, help="r/n: render what rank r of n would, on one GPU, no communication")
     args = ap.parse_args(argv)
@@ -191,6 +206,9 @@ def main():
     ctx.set_camera(cam)
     ctx.set_pipeline(args.pipeline)
     nbuf = min(8, max(2 if use_comm else 1, args.inflight))
+    batch = args.batch if args.batch > 0 else DEFAULT_BATCH.get(world if as_rank is None else as_rank[1], 4 if world > 8 else 1)
+    if args.spp > 1:
+        batch = 1            # a multi-sample frame is already many launches
     waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
     if args.pipeline == 1:
         ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and
@@ -200,13 +218,14 @@ def main():
                   mirror_mask=args.mirror, spp=args.spp)
     ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device="cuda",
                      dist=dist if use_comm else None, want_hits=bool(args.hits), force_comm=force_comm,
-                     first_frame=2, params=params, as_rank=as_rank)
+                     first_frame=2, params=params, as_rank=as_rank, batch=batch)
 
     # ---- ray count (untimed counting pass of the first and the last timed frame) ---------------------
     def count(frame):
         c, d, h = ring._ptrs(0)
         ctx.set_stream(ring.streams[0].cuda_stream)
         ctx.bind_outputs(c, d, h)
+        ctx.set_batch(1, 0)
         ctx.set_params(frame, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
         return ctx.count_frame()
 
@@ -220,15 +239,19 @@ def main():
         dist.all_reduce(counts)
     rays, iters, alg_bytes, pixels, nan_rays = [float(v) for v in counts.tolist()]
 
-    for _ in range(args.warmup):
-        ring.step()
+    def run_frames(n):      # exactly n frames: whole batches, then a partial one
+        while n > 0:
+            k = min(batch, n)
+            ring.step(k)
+            n -= k
+
+    run_frames(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ring.timing = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ring.step()
+    run_frames(args.steps)
     torch.cuda.synchronize()
     ring.timing = False
     if world > 1:
@@ -250,24 +273,26 @@ def main():
             step *= 4
         rows_ok = ring.rendered_rows_mask().numpy()
         bad, npx, frames = 0, 0, []
-        for b in range(nbuf):
-            if ring.frame_of[b] is None or ring.frame_of[b] < first_timed:
-                continue
-            imgs = ring.frame_images(b)
+        # of every dispatch the ring still holds: its first and its last frame (timed ones only)
+        held = sorted({(b, k) for b in range(nbuf) if ring.frame_of[b] is not None for k in (0, ring.count_of[b] - 1)
+                       if ring.frame_of[b] + k >= first_timed})
+        for b, k in held:
+            imgs = ring.frame_images(b, k)
             fr = imgs[0]
             col = imgs[1].cpu().numpy().view(np.uint8).reshape(H_total, W, 4)
             dep = imgs[2].cpu().numpy()
-            ref = oracle.render(pool, W, H_total, cam, fr, args.mode, bounces=args.bounces, mirror_mask=args.mirror,
-                                spp=args.spp, xstep=step, ystep=step, want_hits=False)
             ys = np.flatnonzero(rows_ok)[::step]      # every step-th row of those this run rendered
-            sub = np.ix_(ys, np.arange(0, W, step))
-            bad += int((col[sub] != ref["rgba"][sub]).any(axis=2).sum())
-            bad += int((dep.view(np.uint32)[sub] != ref["depth"].view(np.uint32)[sub]).sum())
-            npx += int(ys.size * len(range(0, W, step)))
+            xs = np.arange(0, W, step)
+            for y in ys:                               # the oracle on exactly those rows
+                ref = oracle.render(pool, W, H_total, cam, fr, args.mode, bounces=args.bounces, mirror_mask=args.mirror,
+                                    spp=args.spp, rows=(int(y), int(y) + 1), xstep=step, want_hits=False)
+                bad += int((col[y, xs] != ref["rgba"][y, xs]).any(axis=1).sum())
+                bad += int((dep.view(np.uint32)[y, xs] != ref["depth"].view(np.uint32)[y, xs]).sum())
+            npx += int(ys.size * xs.size)
             frames.append(int(fr))
         verified = bad == 0 and npx > 0
-        vinfo = "frames %s as left by the timed region (%d in flight), every %d-th pixel in x and y (%d pixels): " \
-                "rgba8 + depth bits vs the CPU oracle, %d mismatches" % (frames, nbuf, step, npx, bad)
+        vinfo = "frames %s as left by the timed region (%d dispatches in flight x %d frames), every %d-th pixel in x and y " \
+                "(%d pixels): rgba8 + depth bits vs the CPU oracle, %d mismatches" % (frames, nbuf, batch, step, npx, bad)
 
     # ---- kernel time by HIP events on the dispatch streams; then one frame at a time with the GPU to itself ----
     kernel_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ring.launch_events]))  # with nbuf launches in flight
@@ -275,9 +300,9 @@ def main():
         ctx.set_tuning(0, args.thresh)   # one frame at a time: fill the GPU
     c0, d0, h0 = ring._ptrs(0)
     ctx.bind_outputs(c0, d0, h0)
+    ctx.set_batch(1, 0)
     ctx.set_params(first_timed, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
-    kms = ctx.time_frames(2, max(5, min(args.steps, 30)))
-    kernel_ms_isolated = float(np.mean(kms))
+    kernel_ms_isolated = float(np.mean(ctx.time_frames(2, max(5, min(args.steps, 30))))) if args.isolated else None
     out_bytes_px = 8 + (16 if args.hits else 0)
     my_alg = mine[2] + mine[3] * out_bytes_px
 
@@ -288,28 +313,31 @@ def main():
         # `nbuf` launches share the GPU at any time, each for `kernel_ms`; the device-level rate the HBM
         # roofline is about is bytes per launch / (timed region / launches).  With one frame in flight the two
         # are the same number.
-        achieved_per_launch = my_alg / (kernel_ms * 1e-3) / 1e9
+        achieved_per_launch = my_alg * batch / (kernel_ms * 1e-3) / 1e9
         achieved = my_alg / (elapsed / args.steps) / 1e9
         key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (args.size, W, H_total, args.mode, args.bounces, args.spp, args.pipeline, nbuf)
+        if batch > 1:
+            key += "_B%d" % batch
         pmc = pmc_for(key) if world == 1 and as_rank is None else None
         roof = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": (int(pmc["fetch_size_kb"] * 1024 * 2 + pmc["write_size_kb"] * 1024) if pmc else None),
-            "kernel_ms": round(kernel_ms, 4), "launches_in_flight": nbuf,
+            "traffic": (int((pmc["fetch_size_kb"] * 1024 * 2 + pmc["write_size_kb"] * 1024) / batch) if pmc else None),
+            "kernel_ms": round(kernel_ms, 4), "launches_in_flight": nbuf, "frames_per_launch": batch,
             "achieved_per_launch": round(achieved_per_launch, 2),
-            "kernel_ms_isolated": round(kernel_ms_isolated, 4), "alg_bytes_per_launch": int(my_alg),
-            "note": "kernel_ms > ms_per_step because %d launches overlap; achieved = bytes per launch / ms_per_step "
-                    "(device level), achieved_per_launch = bytes / kernel_ms; kernel_ms_isolated = one frame at a "
-                    "time, GPU filled by one launch" % nbuf,
+            "kernel_ms_isolated": round(kernel_ms_isolated, 4) if kernel_ms_isolated is not None else None,
+            "alg_bytes_per_launch": int(my_alg * batch),
+            "note": "a launch carries %d frame(s) and %d launches overlap, so kernel_ms > ms_per_step (= one frame); achieved = "
+                    "bytes per frame / ms_per_step (device level), achieved_per_launch = bytes per launch / kernel_ms; "
+                    "kernel_ms_isolated = one frame at a time, GPU filled by one launch; traffic is per frame" % (batch, nbuf),
         }
         if pmc:
             # the roof that binds: instruction issue.  Wave-level VALU instructions per launch x 2.5 cycles over
             # what 1024 SIMDs offer in one step; lane utilisation = thread-cycles / (64 x active VALU cycles)
             roof["binding_roof"] = {
                 "kind": "valu-issue",
-                "valu_insts_per_launch": int(pmc["sq_insts_valu"]),
-                "valu_issue_frac": round(pmc["sq_insts_valu"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4),
+                "valu_insts_per_frame": int(pmc["sq_insts_valu"] / batch),
+                "valu_issue_frac": round(pmc["sq_insts_valu"] / batch * VALU_CYCLES / (SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4),
                 "valu_lane_util": round(pmc["sq_thread_cycles_valu"] / (64.0 * pmc["sq_active_inst_valu"]), 4),
                 "src_hash": pmc["src_hash"], "from": "profiles/pmc_per_launch.json",
             }
@@ -331,7 +359,8 @@ def main():
                                 args.spp, args.camera, first_timed, last_timed, args.pipeline, stripes),
                 "rays_per_frame": int(round(rays)), "iterations_per_ray": round(iters / max(rays, 1), 2),
                 "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": int(round(nan_rays)),
-                "scene_build_s": round(t_build, 2), "frames_in_flight": nbuf, "use_beam": args.beam,
+                "scene_build_s": round(t_build, 2), "frames_in_flight": nbuf * batch, "launches_in_flight": nbuf,
+                "frames_per_launch": batch, "use_beam": args.beam,
                 "verification": vinfo,
             },
             "roofline": roof,

@@ -35,6 +35,8 @@ struct svo_ctx {
   bool rows_set = false;
   int row_step = 1, out_y0 = 0, n_tile_rows = -1;  // stripe mode (svo_set_stripes); n_tile_rows < 0 = band mode
   int frame_number = 2, render_mode = 2, buffer_end = 0, use_beam = 0, bounces = 2, spp = 1, progressive = 0;
+  int batch = 1;                 // frames per dispatch (svo_set_batch)
+  uint64_t frame_stride = 0;     // elements between consecutive frames of a batch in each output
   uint32_t mirror_mask = 0;
   int pipeline = 0;
   int write_hits = 1;
@@ -383,6 +385,15 @@ int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_sixteenths)
   return SVO_OK;
 }
 
+int svo_set_batch(svo_ctx *c, int nframes, uint64_t frame_stride) {
+  if (!c || nframes < 1 || nframes > 64) return fail(c, SVO_E_INVALID, "svo_set_batch: 1..64 frames");
+  if (nframes > 1 && frame_stride == 0) return fail(c, SVO_E_INVALID, "svo_set_batch: frame_stride must cover one frame's outputs");
+  if (frame_stride * (uint64_t)nframes >= (1ull << 32)) return fail(c, SVO_E_INVALID, "svo_set_batch: batch too large for 32-bit output indices");
+  c->batch = nframes;
+  c->frame_stride = frame_stride;
+  return SVO_OK;
+}
+
 int svo_set_progressive(svo_ctx *c, int enabled) {
   if (!c) return SVO_E_INVALID;
   c->progressive = enabled ? 1 : 0;
@@ -429,6 +440,7 @@ static int make_frame(svo_ctx *c, Frame &f) {
   f.write_hits = (c->write_hits && c->d_hits) ? 1 : 0;
   f.use_beam = 0; f.beam_w = 0; f.beam = nullptr;
   f.progressive = c->progressive;
+  f.batch = 1; f.frame_stride = 0;
   if (!c->external_outputs && c->n_tile_rows > 0) {
     // packed stripes land at output rows out_y0 + 8 j + ly: they must stay inside the library's W x H images
     // (caller-owned gather buffers are the caller's to size, see svo_bind_outputs)
@@ -477,7 +489,7 @@ static int launch_beam(svo_ctx *c, Frame &f, int &set) {
   return SVO_OK;
 }
 
-static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count);
+static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *color, float *depth, uint4 *hits);
 
 static int launch_frame(svo_ctx *c, bool count) {
   Frame f;
@@ -489,7 +501,22 @@ static int launch_frame(svo_ctx *c, bool count) {
     rc = launch_beam(c, f, beam_set);
     if (rc) return rc;
   }
-  rc = launch_frame_kernels(c, f, count);
+  const int nb = count ? 1 : c->batch;
+  if (nb > 1 && !c->external_outputs)
+    return fail(c, SVO_E_INVALID, "svo_set_batch: a batch renders into caller-owned outputs (svo_bind_outputs)");
+  if (nb > 1 && c->pipeline == 1 && f.spp <= 1 && !f.progressive) {
+    // the persistent pipeline takes the whole batch as one launch: its waves go from frame to frame without a tail
+    f.batch = nb;
+    f.frame_stride = (uint32_t)c->frame_stride;
+    rc = launch_frame_kernels(c, f, count, c->d_color, c->d_depth, c->d_hits);
+  } else {
+    for (int k = 0; k < nb && rc == SVO_OK; k++) {
+      Frame g = f;
+      g.frame_number = f.frame_number + k;
+      const size_t o = (size_t)k * (size_t)c->frame_stride;
+      rc = launch_frame_kernels(c, g, count, c->d_color + o, c->d_depth + o, c->d_hits ? c->d_hits + o : nullptr);
+    }
+  }
   if (rc == SVO_OK && beam_set >= 0) {
     HIPCHK(c, hipEventRecord(c->beam_done[beam_set], c->stream));
     c->beam_used[beam_set] = true;
@@ -497,27 +524,25 @@ static int launch_frame(svo_ctx *c, bool count) {
   return rc;
 }
 
-static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count) {
+static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *color, float *depth, uint4 *hits) {
   int rc = SVO_OK;
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
   if (c->pipeline == 1 && !count) {
-    rc = persist_launch(c->pb, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, out_elems(c, f), c->stream);
+    rc = persist_launch(c->pb, c->d_pool, f, color, depth, hits, out_elems(c, f), c->stream);
     if (rc) return fail(c, SVO_E_HIP, std::string("persistent pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
   if (c->pipeline == 2 && !count) {
-    rc = wavefront_launch(c->wf, c->d_pool, f, c->d_color, c->d_depth, c->d_hits, out_elems(c, f), c->stream);
+    rc = wavefront_launch(c->wf, c->d_pool, f, color, depth, hits, out_elems(c, f), c->stream);
     if (rc) return fail(c, SVO_E_HIP, std::string("wavefront pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
   const int per = (f.ntiles + 7) / 8;
   dim3 grid((unsigned)(per * 8)), block(64);
   if (count)
-    hipLaunchKernelGGL(trace_fused_kernel<true>, grid, block, 0, c->stream, c->d_pool, f, c->d_color, c->d_depth,
-                       c->d_hits, c->d_counters);
+    hipLaunchKernelGGL(trace_fused_kernel<true>, grid, block, 0, c->stream, c->d_pool, f, color, depth, hits, c->d_counters);
   else
-    hipLaunchKernelGGL(trace_fused_kernel<false>, grid, block, 0, c->stream, c->d_pool, f, c->d_color, c->d_depth,
-                       c->d_hits, c->d_counters);
+    hipLaunchKernelGGL(trace_fused_kernel<false>, grid, block, 0, c->stream, c->d_pool, f, color, depth, hits, c->d_counters);
   HIPCHK(c, hipGetLastError());
   return SVO_OK;
 }

@@ -25,6 +25,10 @@ struct Frame {
   // cross-frame accumulation (commented out in the reference, svotrace.comp:712-719): blend with the image the
   // previous frame left in the colour buffer
   int32_t progressive;
+  // several consecutive frames of one camera in one launch (svo_set_batch): frame k renders frameNumber + k into the
+  // outputs at element offset k * frame_stride.  1 = the reference's one dispatch per frame.
+  int32_t batch;
+  uint32_t frame_stride;
 };
 
 // device-side counters of a counted frame

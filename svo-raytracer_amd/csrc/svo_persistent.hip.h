@@ -224,7 +224,8 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         const int first_row = (int)band * a.rows_per_band;
         int band_rows = f.tiles_y - first_row;
         band_rows = band_rows < 0 ? 0 : (band_rows > a.rows_per_band ? a.rows_per_band : band_rows);
-        const uint32_t band_total = (uint32_t)(band_rows * f.tiles_x) * 64u;
+        const uint32_t band_frame = (uint32_t)(band_rows * f.tiles_x) * 64u;   // pixel slots of the band in one frame
+        const uint32_t band_total = band_frame * (uint32_t)f.batch;              // ... and over the launch's frames
 #else
         const int first_tile = (int)band * a.tiles_per_band;
         int band_tiles = f.ntiles - first_tile;
@@ -239,7 +240,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         if (status == ST_IDLE && slot < band_total) {
           const uint32_t l = slot & 63u;
 #if SVO_BAND_COLMAJOR
-          const int j = (int)(slot >> 6);
+          // frames of a batch follow one another inside the band: a wave that runs out of frame k goes on with k + 1
+          const uint32_t fi = f.batch > 1 ? slot / band_frame : 0u;
+          const int j = (int)((slot - fi * band_frame) >> 6);
           int tile_x = j / band_rows;
           const int tile_y = first_row + j % band_rows;
           if (a.reverse) tile_x = f.tiles_x - 1 - tile_x;   // serpentine: this frame ends where the next one starts
@@ -250,7 +253,11 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
           px = tile_x * 8 + (int)(l & 7u);
           py = frame_gy(f, tile_y, (int)(l >> 3));
           if (px < f.width && py < f.y1 && py < f.height) {
+#if SVO_BAND_COLMAJOR
+            pix = fi * f.frame_stride + (uint32_t)frame_oy(f, tile_y, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
+#else
             pix = (uint32_t)frame_oy(f, tile_y, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
+#endif
             d = primary_direction(f, px, py);
             seg = 0u;
             mask = mk(1.f, 1.f, 1.f);
@@ -258,7 +265,11 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             normal = mk(0.f, 0.f, 0.f);
             value = 0u;
             depth = 0.0f;
+#if SVO_BAND_COLMAJOR
+            if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + (int)fi + a.sample));
+#else
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
+#endif
             status = SVO_TRAV_INIT(root, t, cam_o, d, false, beam_start(f, px, py));
           }
         }
@@ -412,7 +423,8 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.tiles_per_band = (f.ntiles + 7) / 8;
   a.rows_per_band = (f.tiles_y + 7) / 8;
   a.thresh_num = b.thresh_num;
-  const int blocks = f.ntiles < b.blocks ? f.ntiles : b.blocks;
+  const long long work = (long long)f.ntiles * (f.batch > 1 ? f.batch : 1);
+  const int blocks = work < (long long)b.blocks ? (int)work : b.blocks;
   // a ring of counter sets: frames may be in flight on different streams at the same time.  A frame's sample launches
   // are ordered by its stream, so they share the frame's set; only another frame's re-use waits (for the event)
   const int hset = (int)(frame_no % kHeadSets);

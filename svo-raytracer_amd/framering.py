@@ -7,13 +7,14 @@ pre-incremented (first frame = 2), the uniforms are set, the frame is dispatched
 are in flight: frame k renders into buffer k % nbuf on stream k % nbuf, and -- with more than one
 rank -- its bands travel to rank 0 on a separate communication stream while frame k + 1 is traced.
 
-Gather buffer of one frame in flight, on every rank:  [world][planes][rows_per_rank][W] 32-bit words,
-planes = colour (rgba8), depth (f32 bits) [+ 4 words of hit record].  A rank renders its stripes PACKED
-into its own chunk (svo_set_stripes with out_row0 = 0, outputs bound at the chunk), so one contiguous
-chunk per rank and ONE gather per frame carry colour and depth together.
+Gather buffer of one dispatch in flight, on every rank:  [world][planes][batch][rows_per_rank][W] 32-bit words,
+planes = colour (rgba8), depth (f32 bits) [+ 4 words of hit record]; `batch` = frames per dispatch (svo_set_batch;
+1 = the reference's one dispatch per frame).  A rank renders its stripes PACKED into its own chunk (svo_set_stripes
+with out_row0 = 0, outputs bound at the chunk, frame k of the batch rows_per_rank * W elements further), so one
+contiguous chunk per rank and ONE gather per dispatch carry colour and depth of all its frames together.
 
 The renderer is duck-typed (hiplib.HipContext on the GPU; tests pass a CPU stand-in):
-  set_stream(ptr) bind_outputs(color_ptr, depth_ptr, hits_ptr) set_params(...) dispatch_async()
+  set_stream(ptr) bind_outputs(color_ptr, depth_ptr, hits_ptr) set_params(...) set_batch(n, stride) dispatch_async()
 """
 import torch
 
@@ -36,7 +37,7 @@ class _NoStream:
 
 class FrameRing:
     def __init__(self, renderer, width, height, world=1, rank=0, nbuf=3, device="cuda", dist=None,
-                 want_hits=False, force_comm=False, first_frame=2, params=None, as_rank=None):
+                 want_hits=False, force_comm=False, first_frame=2, params=None, as_rank=None, batch=1):
         """params: dict(render_mode, buffer_end, use_beam, bounces, mirror_mask, spp) -- constant over the run.
         as_rank = (r, n): render what rank r of n would, without any communication (single-GPU what-if runs)."""
         self.r = renderer
@@ -53,17 +54,19 @@ class FrameRing:
         self.params = dict(render_mode=0, buffer_end=0, use_beam=0, bounces=2, mirror_mask=0, spp=1)
         self.params.update(params or {})
         self.k = 0
+        self.batch = max(1, int(batch))
         self.first_frame = int(first_frame)
         lw, lr = (self.world, self.rank) if as_rank is None else (int(as_rank[1]), int(as_rank[0]))
         self.layout_world = lw
         self.s_first, self.s_step, self.s_n, _, self.rows_per_rank = stripe_layout(self.H, lw, lr)
         self.chunk_world = self.world if as_rank is None else 1
         rpr = self.rows_per_rank
-        # [world][planes][rpr][W] words; rank r's chunk is self.buf[b][r]
-        self.buf = [torch.zeros((self.chunk_world, self.planes, rpr, self.W), dtype=torch.int32, device=device)
+        # [world][planes][batch][rpr][W] words; rank r's chunk is self.buf[b][r]
+        self.buf = [torch.zeros((self.chunk_world, self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
                     for _ in range(self.nbuf)]
-        self.frame_of = [None] * self.nbuf          # frameNumber held by each buffer
-        self.scratch = (torch.zeros((self.planes, rpr, self.W), dtype=torch.int32, device=device)
+        self.frame_of = [None] * self.nbuf          # first frameNumber held by each buffer
+        self.count_of = [0] * self.nbuf             # frames it holds
+        self.scratch = (torch.zeros((self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
                         if self.use_comm and self.rank == 0 else None)
         if self.cuda:
             main = torch.cuda.current_stream()
@@ -77,6 +80,7 @@ class FrameRing:
         self.gathered = [None] * self.nbuf          # event: the gather that last read buffer b has finished
         self.timing = False
         self.launch_events = []
+        self.dispatches = 0
         self.my_chunk = self.rank if as_rank is None else 0
         if hasattr(self.r, "set_stripes"):
             self.r.set_stripes(self.s_first, self.s_step, self.s_n, 0)
@@ -86,13 +90,16 @@ class FrameRing:
         mine = self.buf[b][self.my_chunk]
         word = 4
         base = mine.data_ptr()
-        plane = self.rows_per_rank * self.W * word
+        plane = self.batch * self.rows_per_rank * self.W * word
         return base, base + plane, (base + 2 * plane if self.want_hits else None)
 
-    def step(self):
-        b = self.k % self.nbuf
+    def step(self, nframes=None):
+        """Dispatch the next `nframes` frames (default: a whole batch) as one dispatch; returns the first frameNumber."""
+        n = self.batch if nframes is None else max(1, min(int(nframes), self.batch))
+        b = self.dispatches % self.nbuf
+        self.dispatches += 1
         frame = self.first_frame + self.k
-        self.k += 1
+        self.k += n
         stream = self.streams[b]
         self.r.set_stream(stream.cuda_stream)
         if self.gathered[b] is not None:
@@ -101,7 +108,10 @@ class FrameRing:
         self.r.bind_outputs(c, d, h)
         p = self.params
         self.r.set_params(frame, p["render_mode"], p["buffer_end"], p["use_beam"], p["bounces"], p["mirror_mask"], p["spp"])
+        if self.batch > 1 or hasattr(self.r, "set_batch"):
+            self.r.set_batch(n, self.rows_per_rank * self.W)
         self.frame_of[b] = frame
+        self.count_of[b] = n
         if self.timing and self.cuda:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -147,10 +157,10 @@ class FrameRing:
             torch.cuda.synchronize()
             self.r.set_stream(self.streams[0].cuda_stream)
 
-    def frame_images(self, b):
-        """(frameNumber, colour [H][W] int32, depth [H][W] float32[, hits [H][W][4] int32]) of buffer b in frame
-        order, on the frame owner (rank 0) after drain(); with as_rank only the rows that rank rendered are valid."""
-        full = self.buf[b]                      # [chunks][planes][rpr][W]
+    def frame_images(self, b, k=0):
+        """(frameNumber, colour [H][W] int32, depth [H][W] float32[, hits [H][W][4] int32]) of frame k of buffer b in
+        frame order, on the frame owner (rank 0) after drain(); with as_rank only the rows that rank rendered are valid."""
+        full = self.buf[b][:, :, k]             # [chunks][planes][rpr][W]
         per = self.rows_per_rank // TILE
         cw = full.shape[0]
         lw = self.layout_world
@@ -170,9 +180,9 @@ class FrameRing:
         depth = order(full[:, 1]).view(torch.float32)
         if self.want_hits:
             # the hit image is pixel-major (16 bytes per pixel) inside the chunk's last four plane-sized slots
-            hits = order(full[:, 2:6].reshape(cw, self.rows_per_rank, self.W, 4))
-            return self.frame_of[b], color, depth, hits
-        return self.frame_of[b], color, depth
+            hits = order(self.buf[b][:, 2:6].reshape(cw, self.batch, self.rows_per_rank, self.W, 4)[:, k])
+            return self.frame_of[b] + k, color, depth, hits
+        return self.frame_of[b] + k, color, depth
 
     def rendered_rows_mask(self):
         """bool [H]: rows this rank's stripes cover (all rows on the owner after a gather)."""

@@ -15,7 +15,7 @@ HIT_DTYPE = np.dtype([("pointer", "<u4"), ("raw_normal", "<u2"), ("value", "u1")
 EXPORTS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
     "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_build_from_voxels", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
-    "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
+    "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_set_batch", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel", "svo_read_beam",
     "svo_output_device_ptrs",
 ]
@@ -70,6 +70,7 @@ def lib(path=None):
         L.svo_set_pipeline.argtypes = [vp, ci]
         L.svo_set_hit_records.argtypes = [vp, ci]
         L.svo_set_progressive.argtypes = [vp, ci]
+        L.svo_set_batch.argtypes = [vp, ci, u64]
         L.svo_set_tuning.argtypes = [vp, ci, ci]
         L.svo_dispatch.argtypes = [vp]
         L.svo_dispatch_async.argtypes = [vp]
@@ -197,6 +198,9 @@ class HipContext:
 
     def set_tuning(self, waves_per_cu=0, round_threshold_sixteenths=0):
         self._chk(self._L.svo_set_tuning(self._h, int(waves_per_cu), int(round_threshold_sixteenths)))
+
+    def set_batch(self, nframes, frame_stride=0):
+        self._chk(self._L.svo_set_batch(self._h, int(nframes), int(frame_stride)))
 
     def set_progressive(self, on):
         self._chk(self._L.svo_set_progressive(self._h, 1 if on else 0))

@@ -26,6 +26,10 @@ class OracleStripeRenderer:
         self.ptrs = None
         self.params = None
         self.calls = []
+        self.batch, self.frame_stride = 1, 0
+
+    def set_batch(self, n, stride):
+        self.batch, self.frame_stride = n, stride
 
     def set_stripes(self, first, step, n, out0):
         self.stripes = (first, step, n, out0)
@@ -41,16 +45,21 @@ class OracleStripeRenderer:
 
     def dispatch_async(self):
         from oracle import oracle
+        for k in range(self.batch):        # frame k of the batch: frameNumber + k, outputs frame_stride elements further
+            self._one(self.params[0] + k, k * self.frame_stride)
+
+    def _one(self, frame, eoff):
+        from oracle import oracle
         first, step, n, out0 = self.stripes
-        frame, mode, bounces, mirror, spp = self.params
+        _, mode, bounces, mirror, spp = self.params
         self.calls.append(frame)
         cptr, dptr, hptr = self.ptrs
         rows = out0 + 8 * n
-        col = np.ctypeslib.as_array((ctypes.c_uint32 * (rows * self.w)).from_address(cptr)).reshape(rows, self.w)
-        dep = np.ctypeslib.as_array((ctypes.c_float * (rows * self.w)).from_address(dptr)).reshape(rows, self.w)
+        col = np.ctypeslib.as_array((ctypes.c_uint32 * (rows * self.w)).from_address(cptr + 4 * eoff)).reshape(rows, self.w)
+        dep = np.ctypeslib.as_array((ctypes.c_float * (rows * self.w)).from_address(dptr + 4 * eoff)).reshape(rows, self.w)
         hit = None
         if hptr:
-            hit = np.ctypeslib.as_array((ctypes.c_uint32 * (rows * self.w * 4)).from_address(hptr)).reshape(rows, self.w, 4)
+            hit = np.ctypeslib.as_array((ctypes.c_uint32 * (rows * self.w * 4)).from_address(hptr + 16 * eoff)).reshape(rows, self.w, 4)
         for j in range(n):
             y0 = (first + j * step) * 8
             y1 = min(self.h, y0 + 8)
@@ -73,7 +82,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, nbuf, steps, want_hits, out_path):
+def _worker(rank, world, port, w, h, nbuf, steps, want_hits, out_path, batch=1):
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -86,37 +95,44 @@ def _worker(rank, world, port, w, h, nbuf, steps, want_hits, out_path):
     dpool = replicate_pool(dist, pool, rank, world, device="cpu")   # ... and replicated by one broadcast
     rend = OracleStripeRenderer(dpool.numpy(), w, h, CAMERAS["K1"])
     ring = FrameRing(rend, w, h, world=world, rank=rank, nbuf=nbuf, device="cpu", dist=dist, want_hits=want_hits,
-                     first_frame=2, params=dict(render_mode=0, buffer_end=int(dpool.numel())))
-    for _ in range(steps):
-        ring.step()
+                     first_frame=2, params=dict(render_mode=0, buffer_end=int(dpool.numel())), batch=batch)
+    left = steps
+    while left > 0:                                    # `steps` frames, the last dispatch a partial batch if need be
+        n = min(batch, left)
+        ring.step(n)
+        left -= n
     ring.drain()
-    assert rend.calls == list(range(2, 2 + steps))    # frameNumber pre-incremented once per step (Main.java:275)
+    assert rend.calls == list(range(2, 2 + steps))    # frameNumber pre-incremented once per frame (Main.java:275)
     if rank == 0:
-        out = {}
+        out, i = {}, 0
         for b in range(nbuf):
-            imgs = ring.frame_images(b)
-            out["frame%d" % b] = np.int64(imgs[0])
-            out["color%d" % b] = imgs[1].numpy()
-            out["depth%d" % b] = imgs[2].numpy()
-            if want_hits:
-                out["hits%d" % b] = imgs[3].numpy()
+            for k in range(ring.count_of[b]):
+                imgs = ring.frame_images(b, k)
+                out["frame%d" % i] = np.int64(imgs[0])
+                out["color%d" % i] = imgs[1].numpy()
+                out["depth%d" % i] = imgs[2].numpy()
+                if want_hits:
+                    out["hits%d" % i] = imgs[3].numpy()
+                i += 1
+        out["nframes"] = np.int64(i)
         np.savez(out_path, **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,nbuf,steps,want_hits", [(2, 96, 3, 5, False), (2, 100, 2, 3, True), (3, 116, 3, 4, False)])
-def test_frame_ring_over_gloo_reassembles_every_frame_in_the_ring(tmp_path, world, h, nbuf, steps, want_hits):
+@pytest.mark.parametrize("world,h,nbuf,steps,want_hits,batch", [(2, 96, 3, 5, False, 1), (2, 100, 2, 3, True, 1),
+                                                                   (3, 116, 3, 4, False, 1), (2, 100, 2, 7, True, 3)])
+def test_frame_ring_over_gloo_reassembles_every_frame_in_the_ring(tmp_path, world, h, nbuf, steps, want_hits, batch):
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd.cameras import CAMERAS
     from oracle import oracle
     w = 64
     out = str(tmp_path / "ring.npz")
-    mp.spawn(_worker, args=(world, _free_port(), w, h, nbuf, steps, want_hits, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, nbuf, steps, want_hits, out, batch), nprocs=world, join=True)
     z = np.load(out)
     pool, _ = scene.build_scene(64)
     seen = set()
-    for b in range(nbuf):
+    for b in range(int(z["nframes"])):
         frame = int(z["frame%d" % b])
         seen.add(frame)
         full = oracle.render(pool, w, h, CAMERAS["K1"], frame, 0)
@@ -124,8 +140,11 @@ def test_frame_ring_over_gloo_reassembles_every_frame_in_the_ring(tmp_path, worl
         assert (z["depth%d" % b].view(np.uint32) == full["depth"].view(np.uint32)).all(), (b, frame)
         if want_hits:
             assert (z["hits%d" % b].astype(np.uint32).reshape(h, w, 4) == full["hits"].view(np.uint32).reshape(h, w, 4)).all()
-    # the ring holds the last nbuf frames of the run, all different
-    assert seen == set(range(2 + steps - nbuf, 2 + steps))
+    # the ring holds the frames of the last nbuf dispatches of the run, all different
+    if batch == 1:
+        assert seen == set(range(2 + steps - nbuf, 2 + steps))
+    else:
+        assert len(seen) == int(z["nframes"]) and max(seen) == 1 + steps
 
 
 def test_what_if_rank_layout_matches_the_real_split():

@@ -260,3 +260,82 @@ def test_packed_stripes_with_samples_beyond_the_frame_height(ctx, pipeline):
     finally:
         ctx.bind_outputs(None, None, None)
         ctx.set_rows(0, h)
+
+
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_batched_dispatch_equals_one_dispatch_per_frame(ctx, pipeline):
+    """svo_set_batch: one dispatch renders frameNumber .. frameNumber + n - 1 (on the persistent pipeline as ONE launch whose
+    waves run from frame to frame); every frame's bytes are those of a dispatch of its own -- also with the beam
+    pre-pass, with packed stripes, and with several batches in flight on different streams."""
+    import torch
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    from svo_raytracer_amd.tiles import stripe_layout
+    pool, _ = scene.build_scene(1024)
+    w, h, nb = 640, 360, 3
+    ctx.set_pipeline(pipeline)
+    ctx.set_tuning(5, 9)
+    ref = {}
+
+    def alone(frame, mode, beam):
+        key = (frame, mode, beam)
+        if key not in ref:
+            ctx.set_batch(1, 0)
+            ctx.bind_outputs(None, None, None)
+            ctx.set_rows(0, h)
+            ref[key] = ctx.render(pool if not ref else None, w, h, CAMERAS["K1"], frame, mode, use_beam=beam)
+        return ref[key]
+
+    try:
+        for mode, beam in ((0, 0), (2, 0), (0, 1)):
+            for f in range(2, 2 + 2 * nb):
+                alone(f, mode, beam)
+            # two batches of three frames in flight on two streams
+            stride = w * h
+            col = [torch.zeros((nb, h, w), dtype=torch.int32, device="cuda") for _ in range(2)]
+            dep = [torch.zeros((nb, h, w), dtype=torch.float32, device="cuda") for _ in range(2)]
+            hit = [torch.zeros((nb, h, w, 4), dtype=torch.int32, device="cuda") for _ in range(2)]
+            streams = [torch.cuda.Stream() for _ in range(2)]
+            torch.cuda.synchronize()
+            ctx.set_batch(nb, stride)
+            for b in range(2):
+                ctx.set_stream(streams[b].cuda_stream)
+                ctx.bind_outputs(col[b].data_ptr(), dep[b].data_ptr(), hit[b].data_ptr())
+                ctx.set_params(2 + b * nb, mode, 0, beam, 2, 0, 1)
+                ctx.dispatch_async()
+            torch.cuda.synchronize()
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            for b in range(2):
+                for k in range(nb):
+                    want = alone(2 + b * nb + k, mode, beam)
+                    tag = (pipeline, mode, beam, b, k)
+                    assert np.array_equal(col[b][k].cpu().numpy().view(np.uint8).reshape(h, w, 4), want["rgba"]), tag
+                    assert np.array_equal(dep[b][k].cpu().numpy().view(np.uint32), want["depth"].view(np.uint32)), tag
+                    got_h = hit[b][k].cpu().numpy().reshape(-1, 4).copy().view(hiplib.HIT_DTYPE).reshape(h, w)
+                    assert got_h.tobytes() == want["hits"].tobytes(), tag
+        # a batch of packed stripes (what one rank of three renders)
+        first, step, n, out0, rows = stripe_layout(h, 3, 1)
+        colS = torch.zeros((nb, rows, w), dtype=torch.int32, device="cuda")
+        depS = torch.zeros((nb, rows, w), dtype=torch.float32, device="cuda")
+        ctx.bind_outputs(colS.data_ptr(), depS.data_ptr(), None)
+        ctx.set_stripes(first, step, n, 0)
+        ctx.set_batch(nb, rows * w)
+        ctx.set_params(2, 0, 0, 0, 2, 0, 1)
+        ctx.dispatch()
+        for k in range(nb):
+            want = alone(2 + k, 0, 0)
+            for j in range(n):
+                y = (first + j * step) * 8
+                ys = min(8, h - y)
+                assert np.array_equal(colS[k, 8 * j:8 * j + ys].cpu().numpy().view(np.uint8).reshape(ys, w, 4), want["rgba"][y:y + ys]), (k, j)
+        # library-owned images cannot hold a batch
+        ctx.bind_outputs(None, None, None)
+        ctx.set_rows(0, h)
+        ctx.set_batch(2, w * h)
+        with pytest.raises(hiplib.SvoError):
+            ctx.dispatch()
+    finally:
+        ctx.set_batch(1, 0)
+        ctx.bind_outputs(None, None, None)
+        ctx.set_tuning(0, 0)

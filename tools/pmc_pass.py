@@ -41,6 +41,11 @@ def main():
     a = bench.parse(bench_args)
     nbuf = min(8, max(1, a.inflight))
     key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (a.size, a.width, a.height, a.mode, a.bounces, a.spp, a.pipeline, nbuf)
+    batch = a.batch if a.batch > 0 else bench.DEFAULT_BATCH.get(1, 1)
+    if a.spp > 1:
+        batch = 1
+    if batch > 1:
+        key += "_B%d" % batch
     out_root = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, key))
     os.makedirs(out_root, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
@@ -50,7 +55,7 @@ def main():
         subprocess.call(["rm", "-rf", d])
         cmd = ["timeout", "-s", "KILL", "300", "rocprofv3", "--pmc"] + counters + \
               ["--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-               "--steps", "30", "--warmup", "3", "--cpu-seconds", "0", "--verify", "0"] + bench_args
+               "--steps", "32", "--warmup", "4", "--cpu-seconds", "0", "--verify", "0", "--isolated", "0"] + bench_args
         with open(os.path.join(out_root, name + ".log"), "w") as lf:
             rc = subprocess.call(cmd, cwd="/tmp", env=env, stdout=lf, stderr=subprocess.STDOUT)
         print("pass %s rc %d" % (name, rc), flush=True)
@@ -74,7 +79,7 @@ def main():
         "sq_insts_valu": means["SQ_INSTS_VALU"], "sq_active_inst_valu": means["SQ_ACTIVE_INST_VALU"],
         "sq_thread_cycles_valu": means["SQ_THREAD_CYCLES_VALU"],
         "other": {k: v for k, v in means.items() if k not in need},
-        "how": "rocprofv3 --pmc, separate passes of `bench.py --steps 30 --warmup 3 " + " ".join(bench_args) +
+        "how": "rocprofv3 --pmc, separate passes of `bench.py --steps 32 --warmup 4 --verify 0 --isolated 0 " + " ".join(bench_args) +
                "`, per-dispatch mean over the kernel's launches; traffic = FETCH_SIZE x 2 (gfx950: 128-B requests "
                "tallied at 64 B, profiles/r01_fetch_size_calibration.txt) + WRITE_SIZE, both in KB",
     }
