@@ -153,6 +153,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
+    # the dispatches in flight, the gather and torch's own stream each want a hardware queue of their own; HIP's default
+    # of 4 makes two of the frame streams share one (their launches then serialise).  Read when the runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import numpy as np
     import torch

@@ -69,9 +69,13 @@ class FrameRing:
         self.scratch = (torch.zeros((self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
                         if self.use_comm and self.rank == 0 else None)
         if self.cuda:
+            # one stream of its own per dispatch in flight (not torch's default stream).  HIP maps streams onto a small
+            # number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default): two of these streams on one queue serialise
+            # their launches (3.6 instead of 4.5 Grays/s, tools/r02_streams.sh), so the process should raise the limit
+            # before it touches the GPU -- bench.py sets GPU_MAX_HW_QUEUES=8.
             main = torch.cuda.current_stream()
-            self.streams = [main] + [torch.cuda.Stream() for _ in range(self.nbuf - 1)]
-            for s in self.streams[1:]:
+            self.streams = [torch.cuda.Stream() for _ in range(self.nbuf)]
+            for s in self.streams:
                 s.wait_stream(main)
             self.comm_stream = torch.cuda.Stream() if self.use_comm else None
         else:
