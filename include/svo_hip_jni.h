@@ -60,6 +60,10 @@ jlong Java_src_engine_HipRenderer_nBuildFromHeightmap(void *env, void *cls, jlon
 /* OctreeThread.run / constructInnerOctree over a dense chunk (OctreeThread.java:20-23): address of n^3 voxel bytes,
  * the layout of the reference's voxelBuffer (x | y << log2 n | z << 2 log2 n); returns the pool size or a negative status */
 jlong Java_src_engine_HipRenderer_nBuildFromVoxels(void *env, void *cls, jlong ctx, jlong voxels_addr, jint n);
+/* throughput mode: n consecutive frames of the camera per dispatch into caller-owned device buffers (svo_set_batch,
+ * svo_bind_outputs; device addresses as longs) */
+jint Java_src_engine_HipRenderer_nSetBatch(void *env, void *cls, jlong ctx, jint nframes, jlong frame_stride);
+jint Java_src_engine_HipRenderer_nBindOutputs(void *env, void *cls, jlong ctx, jlong color_dptr, jlong depth_dptr, jlong hits_dptr);
 /* the commented-out cross-frame accumulation of svotrace.comp:712-719 */
 jint Java_src_engine_HipRenderer_nSetProgressive(void *env, void *cls, jlong ctx, jint enabled);
 

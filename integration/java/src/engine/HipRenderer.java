@@ -215,6 +215,8 @@ public class HipRenderer {
   private static native int nReadHits(long ctx, long addr);
   private static native long nBuildFromVoxels(long ctx, long voxelsAddr, int n);
   private static native int nSetProgressive(long ctx, int enabled);
+  private static native int nSetBatch(long ctx, int nframes, long frameStride);
+  private static native int nBindOutputs(long ctx, long colorDevicePtr, long depthDevicePtr, long hitsDevicePtr);
   private static native int nReadBeam(long ctx, long addr);
   private static native long nBuildFromHeightmap(long ctx, long heightAddr, long materialAddr, int n);
   private static native int nReadPixel(long ctx, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);

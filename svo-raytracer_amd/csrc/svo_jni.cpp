@@ -67,6 +67,14 @@ jlong Java_src_engine_HipRenderer_nBuildFromVoxels(void *, void *, jlong ctx, jl
   const int rc = svo_build_from_voxels((svo_ctx *)(intptr_t)ctx, (const uint8_t *)(intptr_t)voxels_addr, n, &nbytes);
   return rc == SVO_OK ? (jlong)nbytes : (jlong)rc;
 }
+jint Java_src_engine_HipRenderer_nSetBatch(void *, void *, jlong ctx, jint nframes, jlong frame_stride) {
+  if (frame_stride < 0) return SVO_E_INVALID;
+  return svo_set_batch((svo_ctx *)(intptr_t)ctx, nframes, (uint64_t)frame_stride);
+}
+jint Java_src_engine_HipRenderer_nBindOutputs(void *, void *, jlong ctx, jlong color_dptr, jlong depth_dptr, jlong hits_dptr) {
+  return svo_bind_outputs((svo_ctx *)(intptr_t)ctx, (void *)(intptr_t)color_dptr, (void *)(intptr_t)depth_dptr,
+                          (void *)(intptr_t)hits_dptr);
+}
 jint Java_src_engine_HipRenderer_nSetProgressive(void *, void *, jlong ctx, jint enabled) {
   return svo_set_progressive((svo_ctx *)(intptr_t)ctx, enabled);
 }
