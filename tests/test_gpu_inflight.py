@@ -356,6 +356,24 @@ def test_batched_dispatch_equals_one_dispatch_per_frame(ctx, pipeline):
                 y = (first + j * step) * 8
                 ys = min(8, h - y)
                 assert np.array_equal(colS[k, 8 * j:8 * j + ys].cpu().numpy().view(np.uint8).reshape(ys, w, 4), want["rgba"][y:y + ys]), (k, j)
+        # a frame smaller than the 8 XCD bands (3 tile rows: five bands are empty), 5 frames per launch
+        tw, th = 44, 20
+        ctx.set_batch(1, 0)
+        ctx.bind_outputs(None, None, None)
+        ctx.set_rows(0, h)
+        small = [ctx.render(None, tw, th, CAMERAS["K1"], 2 + k, 0) for k in range(5)]
+        colT = torch.zeros((5, th, tw), dtype=torch.int32, device="cuda")
+        depT = torch.zeros((5, th, tw), dtype=torch.float32, device="cuda")
+        ctx.bind_outputs(colT.data_ptr(), depT.data_ptr(), None)
+        ctx.set_batch(5, tw * th)
+        ctx.set_params(2, 0, 0, 0, 2, 0, 1)
+        ctx.dispatch()
+        for k in range(5):
+            assert np.array_equal(colT[k].cpu().numpy().view(np.uint8).reshape(th, tw, 4), small[k]["rgba"]), k
+            assert np.array_equal(depT[k].cpu().numpy().view(np.uint32), small[k]["depth"].view(np.uint32)), k
+        ctx.set_batch(1, 0)
+        ctx.bind_outputs(None, None, None)
+        ctx.resize(w, h)
         # library-owned images cannot hold a batch
         ctx.bind_outputs(None, None, None)
         ctx.set_rows(0, h)
