@@ -210,8 +210,6 @@ def main():
     ctx.set_pipeline(args.pipeline)
     nbuf = min(8, max(2 if use_comm else 1, args.inflight))
     batch = args.batch if args.batch > 0 else DEFAULT_BATCH.get(world if as_rank is None else as_rank[1], 4 if world > 8 else 1)
-    if args.spp > 1:
-        batch = 1            # a multi-sample frame is already many launches
     waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
     if args.pipeline == 1:
         ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and

@@ -23,6 +23,7 @@
 #include "svo_trav.h"
 #include "svo_travloop.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace svo {
@@ -365,7 +366,8 @@ __global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t 
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = frame_gy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7);
   if (x >= f.width || y >= f.y1 || y >= f.height) return;
-  const size_t pix = (size_t)frame_oy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7) * f.width + x;
+  const size_t pix = (size_t)blockIdx.z * f.frame_stride +      // frame blockIdx.z of a batch
+                     (size_t)frame_oy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7) * f.width + x;
   const float inv = 1.0f / (float)f.spp;
   const V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
   color[pix] = final_rgba8(f, x, y, col, color + pix);
@@ -375,7 +377,8 @@ __global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t 
 // gather buffers); the colour-sum planes are indexed like the outputs.
 inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f, uint32_t *color, float *depth,
                           uint4 *hits, size_t out_npix, hipStream_t stream) {
-  const size_t npix = out_npix;
+  // the colour-sum planes are indexed like the outputs: a batch needs room for all its frames
+  const size_t npix = f.batch > 1 ? std::max(out_npix, (size_t)f.batch * (size_t)f.frame_stride) : out_npix;
   hipError_t e;
   if (!b.heads) {
     if ((e = hipMalloc((void **)&b.heads, kHeadSets * kHeadWords * sizeof(uint32_t))) != hipSuccess) return (int)e;
@@ -446,7 +449,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   if ((e = hipEventRecord(b.head_done[hset], stream)) != hipSuccess) return (int)e;
   b.head_used[hset] = true;
   if (resolve) {
-    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8));
+    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8), (unsigned)(f.batch > 1 ? f.batch : 1));
     hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, facc, b.npix, color);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     if ((e = hipEventRecord(b.facc_done[fset], stream)) != hipSuccess) return (int)e;

@@ -341,6 +341,20 @@ def test_batched_dispatch_equals_one_dispatch_per_frame(ctx, pipeline):
                     assert np.array_equal(dep[b][k].cpu().numpy().view(np.uint32), want["depth"].view(np.uint32)), tag
                     got_h = hit[b][k].cpu().numpy().reshape(-1, 4).copy().view(hiplib.HIT_DTYPE).reshape(h, w)
                     assert got_h.tobytes() == want["hits"].tobytes(), tag
+        # several samples per pixel in a batch: sample s of all frames is one launch; sums stay in sample order
+        ctx.set_batch(1, 0)
+        ctx.bind_outputs(None, None, None)
+        ctx.set_rows(0, h)
+        want_s = [ctx.render(None, w, h, CAMERAS["K1"], 2 + k, 0, spp=3) for k in range(nb)]
+        colM = torch.zeros((nb, h, w), dtype=torch.int32, device="cuda")
+        depM = torch.zeros((nb, h, w), dtype=torch.float32, device="cuda")
+        ctx.bind_outputs(colM.data_ptr(), depM.data_ptr(), None)
+        ctx.set_batch(nb, w * h)
+        ctx.set_params(2, 0, 0, 0, 2, 0, 3)
+        ctx.dispatch()
+        for k in range(nb):
+            assert np.array_equal(colM[k].cpu().numpy().view(np.uint8).reshape(h, w, 4), want_s[k]["rgba"]), ("spp", k)
+            assert np.array_equal(depM[k].cpu().numpy().view(np.uint32), want_s[k]["depth"].view(np.uint32)), ("spp", k)
         # a batch of packed stripes (what one rank of three renders)
         first, step, n, out0, rows = stripe_layout(h, 3, 1)
         colS = torch.zeros((nb, rows, w), dtype=torch.int32, device="cuda")

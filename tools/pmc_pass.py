@@ -42,8 +42,6 @@ def main():
     nbuf = min(8, max(1, a.inflight))
     key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (a.size, a.width, a.height, a.mode, a.bounces, a.spp, a.pipeline, nbuf)
     batch = a.batch if a.batch > 0 else bench.DEFAULT_BATCH.get(1, 1)
-    if a.spp > 1:
-        batch = 1
     if batch > 1:
         key += "_B%d" % batch
     out_root = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, key))
