@@ -174,8 +174,10 @@ int svo_count_frame(svo_ctx *ctx, svo_stats *out);
 int svo_get_stats(svo_ctx *ctx, svo_stats *out);
 /* use a caller-owned hipStream_t (e.g. torch's current stream) instead of the library's.  May be
  * called between dispatches to alternate streams: with separate output buffers (svo_bind_outputs)
- * up to 4 frames can then be in flight (the library rotates per-frame work counters / queues over a ring of
- * that size), the next frame filling the GPU while the previous one drains its longest paths. */
+ * several frames can then be in flight, the next one filling the GPU while the previous one drains its longest paths.
+ * The library rotates its per-frame work counters / queues / accumulators / beam images over small rings and
+ * orders their re-use with events, so any number of dispatches may be outstanding (more than 8 serialise).
+ * HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): two frame streams on one queue serialise. */
 int svo_set_stream(svo_ctx *ctx, void *hip_stream);
 /* time `iters` back-to-back frames with HIP events on the dispatch stream after `warmup`
  * untimed ones; per-frame milliseconds into ms[iters] */

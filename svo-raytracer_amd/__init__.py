@@ -4,9 +4,10 @@ Only what the hot path needs lives here:
   csrc/    HIP kernels (gfx950) + the C-ABI shared library (include/svo_hip.h)
   host/    C++ host-side mirror of the reference's Renderer / Camera / Octree
   scene/   deterministic procedural SVO scene generator (reference pool layout)
-  *.py     thin ctypes bindings used by tests/ and bench.py
+  *.py     thin ctypes bindings used by tests/ and bench.py; framering.py / tiles.py: frames in flight and the
+           multi-GPU tile-stripe split + gather that bench.py drives
 """
-__all__ = ["scene", "hiplib", "hostlib", "cameras", "tiles"]
+__all__ = ["scene", "hiplib", "hostlib", "cameras", "tiles", "framering"]
 
 
 def one_hip_runtime():
