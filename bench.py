@@ -124,14 +124,18 @@ def launch_ranks(args):
     return subprocess.call(cmd)
 
 
+KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop.h", "svo_trav.h", "svo_device.h", "svo_fused.hip.h",
+                  "svo_kernels.h", "Makefile")
+
+
 def source_hash():
-    """Hash of the kernel sources: PMC figures taken on other sources are not reported."""
+    """Hash of what the dominant kernel (persist_kernel) is compiled from, launch shape included: PMC figures taken on
+    other sources are not reported."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "svo-raytracer_amd", "csrc")
-    for n in sorted(os.listdir(d)):
-        if n.endswith((".h", ".hip")) or n == "Makefile":   # kernels + their build flags (not the forwarding JNI shim)
-            h.update(n.encode())
-            h.update(open(os.path.join(d, n), "rb").read())
+    for n in KERNEL_SOURCES:
+        h.update(n.encode())
+        h.update(open(os.path.join(d, n), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -504,7 +504,10 @@ static int launch_frame(svo_ctx *c, bool count) {
   const int nb = count ? 1 : c->batch;
   if (nb > 1 && !c->external_outputs)
     return fail(c, SVO_E_INVALID, "svo_set_batch: a batch renders into caller-owned outputs (svo_bind_outputs)");
-  if (nb > 1 && c->pipeline == 1 && !f.progressive) {
+  if (nb > 1 && f.progressive)
+    return fail(c, SVO_E_INVALID, "svo_set_batch: cross-frame accumulation blends into ONE image frame after frame; "
+                                  "a batch writes every frame to its own");
+  if (nb > 1 && c->pipeline == 1) {
     // the persistent pipeline takes the whole batch as one launch: its waves go from frame to frame without a tail
     f.batch = nb;
     f.frame_stride = (uint32_t)c->frame_stride;

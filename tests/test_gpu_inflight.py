@@ -388,6 +388,18 @@ def test_batched_dispatch_equals_one_dispatch_per_frame(ctx, pipeline):
         ctx.set_batch(1, 0)
         ctx.bind_outputs(None, None, None)
         ctx.resize(w, h)
+        # cross-frame accumulation and batches exclude each other
+        ctx.set_batch(1, 0)
+        ctx.bind_outputs(colT.data_ptr(), depT.data_ptr(), None)
+        ctx.resize(tw, th)
+        ctx.set_progressive(True)
+        ctx.set_batch(2, tw * th)
+        with pytest.raises(hiplib.SvoError):
+            ctx.dispatch()
+        ctx.set_progressive(False)
+        ctx.set_batch(1, 0)
+        ctx.bind_outputs(None, None, None)
+        ctx.resize(w, h)
         # library-owned images cannot hold a batch
         ctx.bind_outputs(None, None, None)
         ctx.set_rows(0, h)
@@ -395,6 +407,7 @@ def test_batched_dispatch_equals_one_dispatch_per_frame(ctx, pipeline):
         with pytest.raises(hiplib.SvoError):
             ctx.dispatch()
     finally:
+        ctx.set_progressive(False)
         ctx.set_batch(1, 0)
         ctx.bind_outputs(None, None, None)
         ctx.set_tuning(0, 0)
