@@ -388,6 +388,18 @@ def main():
                 cpix += smp["stats"]["pixels"]
                 nframes += 1
                 dt = time.perf_counter() - t1
+            # informational, labelled separately (SURVEY 8d ii): the same oracle on all host cores, a few seconds
+            ncores = os.cpu_count() or 1
+            if ncores > 1:
+                t1 = time.perf_counter()
+                arays, apass = 0, 0
+                while time.perf_counter() - t1 < 4.0 and apass < 64:
+                    smp = oracle.render(pool, W, H, cam, 2 + apass, args.mode, threads=ncores, **okw)
+                    arays += smp["stats"]["rays"]
+                    apass += 1
+                adt = time.perf_counter() - t1
+                line["cpu_all_cores"] = {"value": round(arays / adt / 1e6, 2), "unit": "Mrays/s", "cores": ncores, "kind": "port",
+                                         "sample": "%d full frame(s), OpenMP over rows, %.1f s" % (apass, adt)}
             line["cpu_baseline"] = {
                 "value": round(crays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
                 "sample": "every %d-th pixel in x and y of the same frames, %d pass(es) with frameNumber 2.. "

@@ -49,6 +49,8 @@ def lib():
         L.svo_oracle_render.restype = ctypes.c_int
         L.svo_oracle_render_beam.argtypes = L.svo_oracle_render.argtypes + [ctypes.c_void_p]
         L.svo_oracle_render_beam.restype = ctypes.c_int
+        L.svo_oracle_render_mt.argtypes = L.svo_oracle_render.argtypes + [ctypes.c_int]
+        L.svo_oracle_render_mt.restype = ctypes.c_int
         L.svo_oracle_beam.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(Params), ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_uint64)]
         L.svo_oracle_beam.restype = ctypes.c_int
@@ -91,7 +93,7 @@ def beam(pool, width, height, cam, want_visits=False):
 
 
 def render(pool, width, height, cam, frame_number=2, render_mode=2, bounces=2, mirror_mask=0, spp=1,
-           rows=None, xstep=1, ystep=1, want_hits=True, use_beam=False, last_rgba=None):
+           rows=None, xstep=1, ystep=1, want_hits=True, use_beam=False, last_rgba=None, threads=1):
     """Run the CPU restatement. cam: 15 floats (pos,l1,l2,r1,r2). Returns dict with
     rgba (H,W,4 u8), depth (H,W f32), hits (H,W HIT_DTYPE), stats.  use_beam: primary rays start at the coarse
     pass's distance of their block (see svo_oracle_beam in svo_oracle.c); the result also carries "beam"."""
@@ -105,10 +107,15 @@ def render(pool, width, height, cam, frame_number=2, render_mode=2, bounces=2, m
     depth = np.zeros((height, width), dtype=np.float32)
     hits = np.zeros((height, width), dtype=HIT_DTYPE) if want_hits else None
     st = Stats()
-    rc = lib().svo_oracle_render_beam(pool.ctypes.data, pool.size, ctypes.byref(prm), int(y0), int(y1), int(xstep),
-                                      int(ystep), rgba.ctypes.data, depth.ctypes.data,
-                                      hits.ctypes.data if want_hits else None, ctypes.byref(st),
-                                      tb.ctypes.data if tb is not None else None)
+    if threads > 1 and tb is None and last_rgba is None:   # all host cores (the CPU figure beside the single-thread one)
+        rc = lib().svo_oracle_render_mt(pool.ctypes.data, pool.size, ctypes.byref(prm), int(y0), int(y1), int(xstep),
+                                        int(ystep), rgba.ctypes.data, depth.ctypes.data,
+                                        hits.ctypes.data if want_hits else None, ctypes.byref(st), int(threads))
+    else:
+        rc = lib().svo_oracle_render_beam(pool.ctypes.data, pool.size, ctypes.byref(prm), int(y0), int(y1), int(xstep),
+                                          int(ystep), rgba.ctypes.data, depth.ctypes.data,
+                                          hits.ctypes.data if want_hits else None, ctypes.byref(st),
+                                          tb.ctypes.data if tb is not None else None)
     if rc != 0:
         raise RuntimeError(f"svo_oracle_render rc={rc}")
     return {"rgba": rgba, "depth": depth, "hits": hits, "stats": st.as_dict(), "beam": tb}

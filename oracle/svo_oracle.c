@@ -662,6 +662,47 @@ int svo_oracle_render(const uint8_t *pool, uint64_t pool_len, const svo_oracle_p
   return svo_oracle_render_beam(pool, pool_len, prm, y0, y1, xstep, ystep, rgba, depth_out, hits, stats, NULL);
 }
 
+/* The same frame on `nthreads` host threads (OpenMP; rows are independent, every thread runs the single-threaded function
+ * above on its rows with its own counters, summed at the end): the all-core CPU figure bench.py prints next to the
+ * single-thread baseline.  Identical bytes. */
+int svo_oracle_render_mt(const uint8_t *pool, uint64_t pool_len, const svo_oracle_params *prm, int y0, int y1, int xstep,
+                         int ystep, uint8_t *rgba, float *depth_out, svo_hit *hits, svo_oracle_stats *stats, int nthreads) {
+  if (pool_len < NODE_SIZE || prm->width <= 0 || prm->height <= 0) return 1;
+  if (ystep < 1) ystep = 1;
+  if (y1 > prm->height) y1 = prm->height;
+  const int nrows = y1 > y0 ? (y1 - y0 + ystep - 1) / ystep : 0;
+  svo_oracle_stats total;
+  memset(&total, 0, sizeof total);
+  int rc = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  {
+    svo_oracle_stats mine, row;
+    memset(&mine, 0, sizeof mine);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int i = 0; i < nrows; i++) {
+      const int py = y0 + i * ystep;
+      if (svo_oracle_render_beam(pool, pool_len, prm, py, py + 1, xstep, 1, rgba, depth_out, hits, &row, NULL)) continue;
+      mine.pixels += row.pixels; mine.rays += row.rays; mine.nan_rays += row.nan_rays; mine.iterations += row.iterations;
+      mine.alg_bytes += row.alg_bytes; mine.descends += row.descends; mine.advances += row.advances; mine.pops += row.pops;
+      if (row.max_iter > mine.max_iter) mine.max_iter = row.max_iter;
+    }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+    {
+      total.pixels += mine.pixels; total.rays += mine.rays; total.nan_rays += mine.nan_rays; total.iterations += mine.iterations;
+      total.alg_bytes += mine.alg_bytes; total.descends += mine.descends; total.advances += mine.advances; total.pops += mine.pops;
+      if (mine.max_iter > total.max_iter) total.max_iter = mine.max_iter;
+    }
+  }
+  if (stats) *stats = total;
+  return rc;
+}
+
 /* ------------------------------------------------------------------ beam pre-pass (use_beam)
  *
  * NOT a restatement of the reference: its beam pass (svobeam.comp:617-637, Main.java:257-266, svotrace.comp:438,
