@@ -104,6 +104,29 @@ def parse(argv=None):
     return args
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, cut by a cgroup CPU quota if there is one (os.cpu_count()
+    reports the whole host even inside a limited container)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -389,7 +412,7 @@ def main():
                 nframes += 1
                 dt = time.perf_counter() - t1
             # informational, labelled separately (SURVEY 8d ii): the same oracle on all host cores, a few seconds
-            ncores = os.cpu_count() or 1
+            ncores = usable_cores()
             if ncores > 1:
                 t1 = time.perf_counter()
                 arays, apass = 0, 0
@@ -399,12 +422,13 @@ def main():
                     apass += 1
                 adt = time.perf_counter() - t1
                 line["cpu_all_cores"] = {"value": round(arays / adt / 1e6, 2), "unit": "Mrays/s", "cores": ncores, "kind": "port",
-                                         "sample": "%d full frame(s), OpenMP over rows, %.1f s" % (apass, adt)}
+                                         "sample": "%d full frame(s), OpenMP over rows on the cores this process may use (affinity / cgroup "
+                                                   "quota; os.cpu_count() = %d), %.1f s" % (apass, os.cpu_count() or 0, adt)}
             line["cpu_baseline"] = {
                 "value": round(crays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
                 "sample": "every %d-th pixel in x and y of the same frames, %d pass(es) with frameNumber 2.. "
-                          "(%d pixels, %d rays, %.1f s), single-threaded C oracle; host has %d cores" % (
-                              stepxy, nframes, cpix, crays, dt, os.cpu_count() or 0),
+                          "(%d pixels, %d rays, %.1f s), single-threaded C oracle; this process may use %d of the host's %d cores" % (
+                              stepxy, nframes, cpix, crays, dt, usable_cores(), os.cpu_count() or 0),
             }
         else:
             line["cpu_baseline"] = None
