@@ -725,7 +725,44 @@ typedef struct {
   int mask;        /* child tags */
   float x, y, z;   /* cube origin */
   int next;        /* next child slot to look at */
+  uint32_t path;   /* the cube's octant path from the root, 3 bits per level (x | y << 1 | z << 2) */
 } beam_frame;
+
+/* The top BEAM_TOP levels of a pool may carry no emptiness information: the reference's world builder flags every node of
+ * its all-interior levels (fillEmptyChildren, the chunk nodes, the 512^3 task heads; Octree.java:317-343, 481-502) with
+ * value 1 whether anything lies below or not, and the coarse walk would have to open each of them.  So the walk first
+ * marks, for every node of those levels by its octant path, whether a cast could end in it or below it:
+ *   H(node) = value != 0 and (the cast treats it as a leaf  or  H of one of its children),
+ * children BEAM_TOP + 1 levels down counting by their value alone; the walk then skips cubes of those levels with H = 0.
+ * (A cast cannot end inside such a cube either: it only descends through non-empty nodes.) */
+#define BEAM_TOP 4
+static const int beam_live_off[BEAM_TOP + 2] = {0, 0, 8, 72, 584, 4680};   /* level d starts at (8^d - 8) / 7 */
+
+static int beam_mark(const ctx_t *c, uint32_t base, int mask, int depth, uint32_t path, uint8_t *live) {
+  int any = 0;
+  uint32_t ptr = base;
+  for (int n = 0; n < 8; n++) {
+    const int tag = (mask >> (2 * n)) & 3;
+    const int value = get_byte(c, ptr);
+    int h;
+    if (depth == BEAM_TOP + 1) {
+      h = value != 0;
+    } else {
+      h = 0;
+      if (value != 0) {
+        if (tag != 0) h = 1;
+        else {
+          const Node ch = extract_node(c, ptr);
+          h = ch.cp == 0 ? 1 : beam_mark(c, ptr + (uint32_t)ch.cp, ch.leafMask, depth + 1, path * 8u + (uint32_t)n, live);
+        }
+      }
+      live[beam_live_off[depth] + path * 8u + (uint32_t)n] = (uint8_t)h;
+    }
+    any |= h;
+    ptr += tag == 1 ? LEAF_SIZE : (tag == 3 ? NON_SURFACE_LEAF_SIZE : NODE_SIZE);
+  }
+  return any;
+}
 
 static inline vec3 beam_dir(const svo_oracle_params *prm, float u, float v) {
   const float *c = prm->cam;
@@ -757,6 +794,9 @@ int svo_oracle_beam(const uint8_t *pool, uint64_t pool_len, const svo_oracle_par
   const int cam_ok = beam_camera_ok(prm);
   const vec3 o = v3(prm->cam[0], prm->cam[1], prm->cam[2]);
   const Node root = extract_node(&c, 0);
+  static uint8_t live[4680];
+  memset(live, 0, sizeof live);
+  beam_mark(&c, (uint32_t)root.cp, root.leafMask, 1, 0u, live);
   for (int by = 0; by < bh; by++)
     for (int bx = 0; bx < bw; bx++) {
       float *out = &tbeam[(size_t)by * bw + bx];
@@ -782,6 +822,7 @@ int svo_oracle_beam(const uint8_t *pool, uint64_t pool_len, const svo_oracle_par
         beam_frame st[MAX_DEPTH + 1];
         int sp = 0;
         st[0].base = (uint32_t)root.cp; st[0].mask = root.leafMask; st[0].x = 1.0f; st[0].y = 1.0f; st[0].z = 1.0f; st[0].next = 0;
+        st[0].path = 0u;
         while (sp >= 0) {
           beam_frame *f = &st[sp];
           if (f->next == 8) { sp--; continue; }
@@ -797,7 +838,8 @@ int svo_oracle_beam(const uint8_t *pool, uint64_t pool_len, const svo_oracle_par
             ptr += tg == 1 ? LEAF_SIZE : (tg == 3 ? NON_SURFACE_LEAF_SIZE : NODE_SIZE);
           }
           const int tag = (f->mask >> (2 * nch)) & 3;
-          if (get_byte(&c, ptr) == 0) continue;                        /* empty */
+          const uint32_t cpath = f->path * 8u + (uint32_t)nch;
+          if (sp + 1 <= BEAM_TOP ? !live[beam_live_off[sp + 1] + cpath] : get_byte(&c, ptr) == 0) continue;   /* nothing to meet in it */
           const float lx = f->x + (float)(nch & 1) * size, ly = f->y + (float)((nch >> 1) & 1) * size,
                       lz = f->z + (float)((nch >> 2) & 1) * size;
           const float half = 0.5f * size;
@@ -821,6 +863,7 @@ int svo_oracle_beam(const uint8_t *pool, uint64_t pool_len, const svo_oracle_par
           if (terminal) { best2 = dist2; continue; }
           sp++;
           st[sp].base = ptr + (uint32_t)cp; st[sp].mask = cmask; st[sp].x = lx; st[sp].y = ly; st[sp].z = lz; st[sp].next = 0;
+          st[sp].path = cpath;
         }
       }
       *out = sqrtf(best2) * 0.9990234375f;

@@ -26,8 +26,55 @@ namespace svo {
 
 constexpr int kBeamBlock = 4;   // Main.java:41 beamSquareSize
 
+// The top kBeamTop levels of a pool may carry no emptiness information: the reference's world builder flags every node
+// of its all-interior levels (fillEmptyChildren, the chunk nodes, the 512^3 task heads; Octree.java:317-343, 481-502) with
+// value 1 whether anything lies below or not, and the coarse walk would have to open each of them (80 % of its visits
+// on the 8192^3 scene).  So, once per pool, every node of those levels is marked by its octant path:
+//   H(node) = value != 0 and (the cast treats it as a leaf  or  H of one of its children),
+// children kBeamTop + 1 levels down counting by their value alone; the walk skips cubes of those levels with H = 0 (a
+// cast cannot end inside them either: it only descends through non-empty nodes).  4 680 bytes.
+constexpr int kBeamTop = 4;
+constexpr int kBeamLiveBytes = 4680;
+__host__ __device__ inline int beam_live_off(int depth) { return depth == 1 ? 0 : depth == 2 ? 8 : depth == 3 ? 72 : 584; }
+
+// level `depth` (kBeamTop first, then upwards): one thread per octant path
+__global__ void beam_live_kernel(const uint8_t *pool_base, uint32_t pool_len, int depth, uint8_t *live) {
+  const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
+  if (path >= (1u << (3 * depth))) return;
+  Pool pool;
+  pool.base = pool_base;
+  pool.len = pool_len;
+  uint64_t rec = load_record(pool, 0u);
+  uint32_t base = rec_cp(rec), mask = rec_mask_be(rec), ptr = 0, tag = 0;   // the walk starts at the root's children
+  bool reach = true;
+  for (int l = 1; l <= depth && reach; l++) {
+    const uint32_t n = (path >> (3 * (depth - l))) & 7u;
+    ptr = base + child_offset(mask, n);
+    tag = (mask >> (2u * n)) & 3u;
+    rec = load_record(pool, ptr);
+    if (l < depth) {   // an ancestor: the cast only goes on through a non-empty interior node with a child block
+      reach = rec_value(rec) != 0u && tag == 0u && rec_cp(rec) != 0u;
+      base = ptr + rec_cp(rec);
+      mask = rec_mask_be(rec);
+    }
+  }
+  uint32_t h = 0u;
+  if (reach && rec_value(rec) != 0u) {
+    if (tag != 0u || rec_cp(rec) == 0u) {
+      h = 1u;
+    } else if (depth == kBeamTop) {
+      const uint32_t cb = ptr + rec_cp(rec), cm = rec_mask_be(rec);
+      for (uint32_t n = 0; n < 8u; n++) h |= rec_value(load_record(pool, cb + child_offset(cm, n))) != 0u ? 1u : 0u;
+    } else {
+      for (uint32_t n = 0; n < 8u; n++) h |= live[beam_live_off(depth + 1) + path * 8u + n];
+    }
+  }
+  live[beam_live_off(depth) + path] = (uint8_t)h;
+}
+
 struct BeamArgs {
   const uint8_t *pool;
+  const uint8_t *live;   // H of the top levels, by octant path (beam_live_kernel)
   Frame f;
   float *beam;    // [beam_h][beam_w], whole-frame indexing; only the block rows of this launch's tile rows are written
   int beam_w, beam_h;
@@ -122,6 +169,14 @@ __global__ __launch_bounds__(64) void beam_kernel(const BeamArgs a) {
       const float half = 0.5f * size;
       const V3 m = mk((lx + half) - o.x, (ly + half) - o.y, (lz + half) - o.z);   // cube centre, camera-relative
       bool cand = rec_value(rec) != 0u;                                             // not empty
+      if (depth <= (uint32_t)kBeamTop) {   // top levels: a cast could end in it or below it (octant path from the origin)
+        const uint32_t sh = 13u - depth;
+        const uint32_t xi = (uint32_t)((lx - 1.0f) * 8192.0f) >> sh, yi = (uint32_t)((ly - 1.0f) * 8192.0f) >> sh,
+                       zi = (uint32_t)((lz - 1.0f) * 8192.0f) >> sh;
+        uint32_t path = 0u;
+        for (int b = (int)depth - 1; b >= 0; b--) path = path * 8u + (((xi >> b) & 1u) | (((yi >> b) & 1u) << 1) | (((zi >> b) & 1u) << 2));
+        cand = a.live[beam_live_off((int)depth) + path] != 0u;
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) cand = cand && !(dot3(n[k], m) + an[k] * half < 0.0f);   // not entirely behind a side plane
       const float ddx = fmax_g(fmax_g(lx - o.x, o.x - (lx + size)), 0.0f), ddy = fmax_g(fmax_g(ly - o.y, o.y - (ly + size)), 0.0f),

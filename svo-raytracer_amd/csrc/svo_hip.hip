@@ -56,6 +56,8 @@ struct svo_ctx {
   bool beam_used[kBeamSets] = {};
   size_t beam_cap = 0;
   unsigned beam_frames = 0;
+  uint8_t *d_beam_live = nullptr;   // which nodes of the pool's top levels a cast can end in or below (svo_beam.hip.h)
+  bool beam_live_valid = false;     // cleared by everything that changes the pool
   WavefrontBuffers wf;
   PersistBuffers pb;
   svo_stats stats{};
@@ -119,6 +121,7 @@ int svo_destroy(svo_ctx *c) {
   if (c->d_pool) (void)hipFree(c->d_pool);
   if (c->d_counters) (void)hipFree(c->d_counters);
   for (auto &e : c->beam_done) if (e) (void)hipEventDestroy(e);
+  if (c->d_beam_live) (void)hipFree(c->d_beam_live);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -154,6 +157,7 @@ static int refresh_dword0(svo_ctx *c) {
 }
 
 int svo_pool_reserve(svo_ctx *c, uint64_t nbytes) {
+  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
@@ -166,6 +170,7 @@ int svo_pool_reserve(svo_ctx *c, uint64_t nbytes) {
 }
 
 int svo_pool_upload_device(svo_ctx *c, const void *dptr, uint64_t nbytes) {
+  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
   if (!c || (!dptr && nbytes)) return fail(c, SVO_E_INVALID, "svo_pool_upload_device: null buffer");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
@@ -178,6 +183,7 @@ int svo_pool_upload_device(svo_ctx *c, const void *dptr, uint64_t nbytes) {
 }
 
 int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
+  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
   if (!c || (!host && nbytes)) return fail(c, SVO_E_INVALID, "svo_pool_upload: null buffer");
   HIPCHK(c, hipSetDevice(c->device));
   // frames may be in flight on any stream the caller has handed over (svo_set_stream): the pool changes only
@@ -193,6 +199,7 @@ int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
 }
 
 int svo_pool_update(svo_ctx *c, const void *host_base, uint64_t start, uint64_t end) {
+  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
   if (!c || !host_base) return fail(c, SVO_E_INVALID, "svo_pool_update: null buffer");
   if (start >= end) return fail(c, SVO_E_INVALID, "Update SSBO error: Invalid parameters.");
   if (!c->d_pool) return fail(c, SVO_E_NOPOOL, "svo_pool_update before svo_pool_upload");
@@ -219,6 +226,7 @@ int svo_pool_download(svo_ctx *c, void *host, uint64_t nbytes) {
 }
 
 int svo_pool_device_ptr(svo_ctx *c, void **dptr, uint64_t *nbytes) {
+  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
   if (!c || !dptr) return SVO_E_INVALID;
   *dptr = c->d_pool;
   if (nbytes) *nbytes = c->pool_len;
@@ -239,6 +247,7 @@ __global__ void count_zero_bytes_kernel(const uint8_t *p, size_t n, unsigned int
 }
 
 int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *material, int n, uint64_t *out_nbytes) {
+  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
   if (!c || !height || !material) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: null map");
   if (n < 8 || n > 8192 || (n & (n - 1))) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: n must be a power of two in 8..8192");
   HIPCHK(c, hipSetDevice(c->device));
@@ -278,6 +287,7 @@ int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *
 }
 
 int svo_build_from_voxels(svo_ctx *c, const uint8_t *voxels, int n, uint64_t *out_nbytes) {
+  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
   if (!c || !voxels) return fail(c, SVO_E_INVALID, "svo_build_from_voxels: null grid");
   if (n < 2 || n > 1024 || (n & (n - 1))) return fail(c, SVO_E_INVALID, "svo_build_from_voxels: n must be a power of two in 2..1024");
   HIPCHK(c, hipSetDevice(c->device));
@@ -478,10 +488,24 @@ static int launch_beam(svo_ctx *c, Frame &f, int &set) {
     }
     c->beam_cap = need;
   }
+  if (!c->beam_live_valid) {
+    // once per pool: mark the live nodes of the top levels, bottom-up.  The pool only changes while the device is idle
+    // (the mutators synchronise it), so no frame in flight reads the table now; the marking is complete before this call
+    // returns, whichever stream the next dispatch uses.
+    if (!c->d_beam_live) HIPCHK(c, hipMalloc((void **)&c->d_beam_live, kBeamLiveBytes));
+    for (int d = kBeamTop; d >= 1; d--) {
+      const unsigned n = 1u << (3 * d);
+      hipLaunchKernelGGL(beam_live_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pool, (uint32_t)c->pool_len, d,
+                         c->d_beam_live);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->beam_live_valid = true;
+  }
   set = (int)(c->beam_frames++ % svo_ctx::kBeamSets);
   if (c->beam_used[set]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->beam_done[set], 0));
   BeamArgs a;
-  a.pool = c->d_pool; a.f = f; a.beam = c->d_beam[set]; a.beam_w = bw; a.beam_h = bh;
+  a.pool = c->d_pool; a.live = c->d_beam_live; a.f = f; a.beam = c->d_beam[set]; a.beam_w = bw; a.beam_h = bh;
   a.cam_ok = beam_camera_ok(f.cam);
   hipLaunchKernelGGL(beam_kernel, dim3((unsigned)((bw + 7) / 8), (unsigned)(f.tiles_y * 2)), dim3(64), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
