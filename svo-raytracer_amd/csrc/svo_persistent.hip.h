@@ -81,11 +81,11 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
 #if SVO_ASM_LOOP
 #define SVO_TRAV_T TravRegs
 #define SVO_TRAV_INIT trav_init_regs
-#define SVO_TRAV_RESULT trav_result_regs
+#define SVO_TRAV_RESULT(t, s) trav_result_regs(pool, t, s)
 #else
 #define SVO_TRAV_T Trav
 #define SVO_TRAV_INIT trav_init
-#define SVO_TRAV_RESULT trav_result
+#define SVO_TRAV_RESULT(t, s) trav_result(t, s)
 #endif
 
 #ifndef SVO_BAND_COLMAJOR
@@ -93,6 +93,12 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
 #endif
 #ifndef SVO_SERPENTINE
 #define SVO_SERPENTINE 1
+#endif
+#ifndef SVO_STEAL_NOW
+#define SVO_STEAL_NOW 0
+#endif
+#ifndef SVO_DRAIN_NUM
+#define SVO_DRAIN_NUM 12
 #endif
 #ifndef SVO_PERSIST_WAVES_PER_SIMD
 #define SVO_PERSIST_WAVES_PER_SIMD 5
@@ -121,6 +127,8 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 
 #ifdef SVO_STAMPS
   unsigned long long st_round = 0, st_trav = 0, st_nround = 0, st_ntrip = 0, st_shade = 0, st_load = 0, st_t0 = __builtin_readcyclecounter();
+  const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device
+  unsigned long long st_dry = 0;
 #endif
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
@@ -214,9 +222,12 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     st_shade += __builtin_readcyclecounter() - st_t0;
 #endif
     // ---------------- refill idle lanes: ballot + prefix count, one atomic per wave
-    if (bands_left > 0) {
+    // (a wave whose band is used up tries the next band in its next round; SVO_STEAL_NOW=1 tries it in the same round:
+    // 1-4 % slower -- tools/r03_ab_drain.sh)
+    while (bands_left > 0) {
       const unsigned long long idle = __ballot(status == ST_IDLE);
-      if (idle != 0ull) {
+      if (idle == 0ull) break;
+      {
         const uint32_t n = (uint32_t)__builtin_popcountll(idle);
         const int leader = __builtin_ctzll(idle);
 #if SVO_BAND_COLMAJOR
@@ -277,6 +288,14 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         if (base + n >= band_total) {  // this band is used up: move on (work stealing)
           band = (band + 1u) & 7u;
           bands_left--;
+#ifdef SVO_STAMPS
+          if (bands_left == 0) st_dry = __builtin_amdgcn_s_memrealtime();
+#endif
+#if !SVO_STEAL_NOW
+          break;
+#endif
+        } else {
+          break;
         }
       }
     }
@@ -291,7 +310,10 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     // ---------------- traverse until enough lanes have stopped to make a round worthwhile
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
     // (a fixed "N lanes free" trigger was tried instead of the proportional one: 3 % slower at its best setting)
-    const int threshold = __builtin_amdgcn_readfirstlane(bands_left > 0 ? (active0 * a.thresh_num) / 16 : 0);
+    // once every band is used up a round only serves the lanes that go on with another segment of their path: they should
+    // not wait for the longest cast of the wave (SVO_DRAIN_NUM/16 of the active lanes may still be traversing; 0 = wait for all)
+    const int drained = (active0 * SVO_DRAIN_NUM) / 16 < active0 - 1 ? (active0 * SVO_DRAIN_NUM) / 16 : (active0 > 0 ? active0 - 1 : 0);
+    const int threshold = __builtin_amdgcn_readfirstlane(bands_left > 0 ? (active0 * a.thresh_num) / 16 : drained);
 #if SVO_ASM_LOOP
     {
       const unsigned long long act = __ballot(status == ST_ACTIVE);
@@ -320,6 +342,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #ifdef SVO_STAMPS
   if (lane == 0u) {
     unsigned long long *dbg = (unsigned long long *)(a.heads + 8 * kHeadStride);  // spare words behind the 8 band counters
+    const unsigned long long st_end = __builtin_amdgcn_s_memrealtime();
+    atomicMax(dbg + 6, ~st_begin); atomicMax(dbg + 7, ~st_dry); atomicMax(dbg + 8, st_dry); atomicMax(dbg + 9, st_end);
+    atomicAdd(dbg + 10, st_end - st_begin); atomicAdd(dbg + 11, st_dry - st_begin);
     atomicAdd(dbg + 0, st_round); atomicAdd(dbg + 1, st_trav); atomicAdd(dbg + 2, st_nround); atomicAdd(dbg + 3, st_ntrip); atomicAdd(dbg + 4, st_shade); atomicAdd(dbg + 5, st_load);
   }
 #endif

@@ -44,7 +44,7 @@ struct BufPool {
 };
 __device__ __forceinline__ BufPool make_bufpool(const uint8_t *base, uint32_t len) {
   BufPool p;
-  p.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(len + 8u), 0x00020000);
+  p.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(len + 16u), 0x00020000);
   return p;
 }
 __device__ __forceinline__ uint64_t load_record(const BufPool &pool, uint32_t p) {

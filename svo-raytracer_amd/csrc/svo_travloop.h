@@ -41,6 +41,43 @@ namespace svo {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// The second dword of a child record (low byte of the child pointer, tag mask) only matters to a lane that can
+// still descend into the child.  SVO_LOAD2_NARROWED=1 asks for it on those lanes only (a ray that stops on an
+// interior or tag-2 record then fetches the dword once, after the loop, in trav_result_regs): measured 2.4 % SLOWER
+// than both dwords for every active lane right behind the address (tools/r03_ab_ld2.sh) -- the texture path's cost
+// is per wave-level load, not per lane, and the narrowed load leaves ~15 instructions later.  Kept as an A/B switch.
+#ifndef SVO_LOAD2_NARROWED
+#define SVO_LOAD2_NARROWED 0
+#endif
+// SVO_LOAD_X3=1: one dword-aligned dwordx3 (it always covers the 7 bytes) + two v_alignbyte_b32, instead of two
+// dword loads of any alignment: one tag lookup per record instead of two, and no second request that finds the
+// line of the first one still on its way from L2.
+#ifndef SVO_LOAD_X3
+#define SVO_LOAD_X3 0
+#endif
+#if SVO_LOAD_X3
+#define SVO_RECORD_LOAD                                                      \
+  "v_and_b32 %[t3], -4, %[cptr]\n\t"                                         \
+  "buffer_load_dwordx3 v[88:90], %[t3], %[rs], 0 offen\n\t"
+#define SVO_RECORD_ALIGN                                                     \
+  "v_alignbyte_b32 v88, v89, v88, %[cptr]\n\t"                               \
+  "v_alignbyte_b32 v89, v90, v89, %[cptr]\n\t"
+#define SVO_LOAD2_NARROW
+#elif SVO_LOAD2_NARROWED
+#define SVO_RECORD_ALIGN
+#define SVO_RECORD_LOAD "buffer_load_dword v88, %[cptr], %[rs], 0 offen\n\t"
+#define SVO_LOAD2_NARROW                                                     \
+  "s_mov_b64 exec, %[sd]\n\t"                                                \
+  "buffer_load_dword v89, %[cptr], %[rs], 0 offen offset:4\n\t"              \
+  "s_mov_b64 exec, %[act]\n\t"
+#else
+#define SVO_RECORD_ALIGN
+#define SVO_RECORD_LOAD                                                      \
+  "buffer_load_dword v88, %[cptr], %[rs], 0 offen\n\t"                       \
+  "buffer_load_dword v89, %[cptr], %[rs], 0 offen offset:4\n\t"
+#define SVO_LOAD2_NARROW
+#endif
+
 
 // per-ray constants and state in the register layout of trav_loop()
 struct TravRegs {
@@ -95,7 +132,7 @@ __device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, 
 
 
 // result part of the cast (svotrace.comp:371-431)
-__device__ __forceinline__ Cast trav_result_regs(const TravRegs &t, int status) {
+__device__ __forceinline__ Cast trav_result_regs(const BufPool &pool, const TravRegs &t, int status) {
   Cast res;
   res.hit = status == ST_HIT;
   res.capped = status == ST_CAPPED;
@@ -107,7 +144,13 @@ __device__ __forceinline__ Cast trav_result_regs(const TravRegs &t, int status) 
   if (!res.hit) return res;
   uint32_t raw = 0u;
   if (t.tag == 1u) raw = (t.rlo >> 8) & 0xffffu;   // packed normal, u16 little-endian in bytes 1..2
-  else if (t.tag != 3u) raw = rec2_mask_be(t.rhi);
+  else if (t.tag != 3u) {
+#if SVO_LOAD2_NARROWED && !SVO_LOAD_X3
+    raw = rec2_mask_be((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pool.rsrc, (int)(t.cptr + 4u), 0, 0));
+#else
+    raw = rec2_mask_be(t.rhi);
+#endif
+  }
   V3 n = mk(0.f, 0.f, 0.f);
   if (raw != 0u) {
     const int r = (int)raw;
@@ -183,8 +226,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_mad_i32_i24 %[cptr], %[t2], -2, %[cptr]\n\t"               // cptr
       // two dword loads: the texture path takes 96 cycles per CU for a wave of misaligned, divergent dwordx2 and
       // 34 for a dword of any alignment (tools/calib_td.hip)
-      "buffer_load_dword v88, %[cptr], %[rs], 0 offen\n\t"
-      "buffer_load_dword v89, %[cptr], %[rs], 0 offen offset:4\n\t"
+      SVO_RECORD_LOAD
       // ---- exit distances of the current cell (svotrace.comp:268-269)
       "v_mul_f32 %[tcx], %[px], %[cx]\n\t"
       "v_pk_mul_f32 v[86:87], v[68:69], %[cyz]\n\t"
@@ -199,6 +241,13 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_cmp_eq_u32_e64 %[sb], %[scale], %[lod]\n\t"              // at the LOD scale
       "v_cmp_le_f32_e64 %[sc], %[tmin], %[t3]\n\t"              // t_min <= tv_max
       "v_cmp_eq_u32_e64 %[sd], 0, %[tag]\n\t"                // interior tag
+      // lane sets, the part that does not need the record (scalar unit, overlaps the load)
+      "s_or_b64 %[se], %[sb], %[sc]\n\t"
+      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // in range & (at LOD | inside): hits or descends if not empty
+      "s_and_b64 %[sd], %[sd], %[sc]\n\t"
+      "s_andn2_b64 %[sd], %[sd], %[sb]\n\t"
+      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // in range & !at LOD & inside & interior tag: descends if it has a child block
+      SVO_LOAD2_NARROW
       // the ADVANCE step of every active lane, computed while the record is in flight (it does not depend on the
       // record); lanes that turn out to hit or descend simply do not commit it
       "v_cmp_le_f32 vcc, %[tcx], %[tcm]\n\t"
@@ -210,13 +259,8 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_cndmask_b32_e64 %[t2], 0, 1, %[sh]\n\t"
       "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], %[sg]\n\t"
       "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], vcc\n\t"   // step mask
-      // lane sets, the part that does not need the record (scalar unit, overlaps the load)
-      "s_or_b64 %[se], %[sb], %[sc]\n\t"
-      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // in range & (at LOD | inside): hits or descends if not empty
-      "s_and_b64 %[sd], %[sd], %[sc]\n\t"
-      "s_andn2_b64 %[sd], %[sd], %[sb]\n\t"
-      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // in range & !at LOD & inside & interior tag: descends if it has a child block
       "s_waitcnt vmcnt(0)\n\t"
+      SVO_RECORD_ALIGN
       "v_cmp_ne_u32_sdwa %[sa], v88, %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // value != 0
       "v_perm_b32 %[t1], v89, v88, %[selcp]\n\t"            // child pointer (big-endian bytes 1..4)
       "v_cmp_ne_u32_e64 vcc, 0, %[t1]\n\t"
@@ -327,7 +371,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
         [lds8] "v"(lds8), [lds2] "v"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
         [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
-      : "vcc", "scc", "memory", "v73", "v86", "v87", "v92", "v93");
+      : "vcc", "scc", "memory", "v73", "v86", "v87", "v90", "v92", "v93");
 }
 
 }  // namespace svo
