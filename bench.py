@@ -162,6 +162,20 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_key(args, width, height, nbuf, batch):
+    """What a set of per-launch PMC figures belongs to (tools/pmc_pass.py writes under the same key)."""
+    key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (args.size, width, height, args.mode, args.bounces, args.spp, args.pipeline, nbuf)
+    if batch > 1:
+        key += "_B%d" % batch
+    if args.beam:
+        key += "_beam"
+    if args.camera != "K1":
+        key += "_" + args.camera
+    if args.mirror:
+        key += "_mirror%x" % args.mirror
+    return key
+
+
 def pmc_for(key):
     """Per-launch PMC means (profiles/pmc_per_launch.json, written by tools/pmc_pass.py on the GPU box from separate
     rocprofv3 --pmc passes of this very command) -- only if they were taken on the current kernel sources."""
@@ -343,9 +357,7 @@ def main():
         # are the same number.
         achieved_per_launch = my_alg * batch / (kernel_ms * 1e-3) / 1e9
         achieved = my_alg / (elapsed / args.steps) / 1e9
-        key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (args.size, W, H_total, args.mode, args.bounces, args.spp, args.pipeline, nbuf)
-        if batch > 1:
-            key += "_B%d" % batch
+        key = pmc_key(args, W, H_total, nbuf, batch)
         pmc = pmc_for(key) if world == 1 and as_rank is None else None
         roof = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -115,3 +115,46 @@ def test_batches_of_hostile_frames(ctx):
     finally:
         ctx.set_batch(1, 0)
         ctx.bind_outputs(None, None, None)
+
+
+def test_largest_pool_and_largest_frame(ctx):
+    """Maximum sizes: a pool one byte short of the reference's limit (a Java byte[] / GL int offsets: 2^31 - 1 bytes,
+    Octree.java:31-36) whose nodes all live in its last megabytes -- every child pointer of the walk is an offset close
+    to 2^31 -- rendered into an 8K frame (7680x4320: 518 400 tiles, 33 M pixels); one byte more is refused."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    from oracle import oracle
+    small, _ = scene.build_scene(256)
+    total = (1 << 31) - 1
+    off = total - small.size
+    big = np.zeros(total, dtype=np.uint8)
+    big[off:] = small
+    cp = int.from_bytes(bytes(small[1:5]), "big", signed=True)
+    big[0] = small[0]
+    big[1:5] = np.frombuffer(int(off + cp).to_bytes(4, "big", signed=True), dtype=np.uint8)   # the root's children: at the far end
+    big[5:7] = small[5:7]
+    assert scene.validate_pool(big)[0] == 0
+    w, h = 7680, 4320
+    sub = (slice(0, h, 89), slice(0, w, 97))
+    refs = {beam: oracle.render(big, w, h, CAMERAS["K1"], 5, 0, xstep=97, ystep=89, use_beam=bool(beam)) for beam in (0, 1)}
+    ref_small = oracle.render(small, w, h, CAMERAS["K1"], 5, 0, xstep=97, ystep=89)
+    first = True
+    for pipeline in PIPELINES:
+        ctx.set_pipeline(pipeline)
+        for beam in (0, 1):
+            got = ctx.render(big if first else None, w, h, CAMERAS["K1"], 5, 0, use_beam=beam)
+            first = False
+            ref = refs[beam]
+            assert (got["rgba"][sub] == ref["rgba"][sub]).all(), (pipeline, beam)
+            assert (got["depth"][sub].view(np.uint32) == ref["depth"][sub].view(np.uint32)).all(), (pipeline, beam)
+            for k in ("pointer", "value", "raw_normal", "level", "iter"):
+                assert (got["hits"][k][sub] == ref["hits"][k][sub]).all(), (pipeline, beam, k)
+            assert int(got["hits"]["pointer"].max()) > (1 << 31) - small.size
+            # the same frame from the small pool: only the pointers move
+            assert (got["rgba"][sub] == ref_small["rgba"][sub]).all()
+            assert (got["hits"]["pointer"][sub].astype(np.int64) - ref_small["hits"]["pointer"][sub].astype(np.int64) ==
+                    np.where(ref_small["hits"]["pointer"][sub] != 0, off, 0)).all()
+    with pytest.raises(hiplib.SvoError):
+        ctx.pool_upload(np.zeros(1 << 31, dtype=np.uint8))
+    ctx.resize(64, 64)   # give the 8K images back

@@ -40,10 +40,8 @@ def main():
     import bench
     a = bench.parse(bench_args)
     nbuf = min(8, max(1, a.inflight))
-    key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (a.size, a.width, a.height, a.mode, a.bounces, a.spp, a.pipeline, nbuf)
     batch = a.batch if a.batch > 0 else bench.DEFAULT_BATCH.get(1, 1)
-    if batch > 1:
-        key += "_B%d" % batch
+    key = bench.pmc_key(a, a.width, a.height, nbuf, batch)
     out_root = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, key))
     os.makedirs(out_root, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")

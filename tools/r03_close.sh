@@ -1,0 +1,29 @@
+#!/bin/bash
+# closing run of a build: whole GPU suite, default bench, PMC passes (default + one frame at a time), kernel traces
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03_close; mkdir -p $O
+python -m pytest tests -q -m gpu 2>&1 | tail -2
+python tools/pmc_pass.py --tag r03 -- > $O/pmc_pass.log 2>&1; tail -1 $O/pmc_pass.log | cut -c1-200
+python tools/pmc_pass.py --tag r03 -- --inflight 1 --batch 1 > $O/pmc_pass1.log 2>&1; tail -1 $O/pmc_pass1.log | cut -c1-200
+cp gpurun_out/pmc_per_launch.json profiles/pmc_per_launch.json
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --inflight 1 --batch 1 --cpu-seconds 0 2>/dev/null | tail -1 > $O/bench_inflight1.json
+python bench.py --beam 1 --cpu-seconds 0 2>/dev/null | tail -1 > $O/bench_beam1.json
+python bench.py --mode 2 --cpu-seconds 0 2>/dev/null | tail -1 > $O/bench_mode2.json
+python bench.py --config C2 --cpu-seconds 0 2>/dev/null | tail -1 > $O/bench_C2.json
+python bench.py --config C4 --cpu-seconds 0 --steps 60 2>/dev/null | tail -1 > $O/bench_C4.json
+python bench.py --config C5 --cpu-seconds 0 --steps 6 --warmup 2 2>/dev/null | tail -1 > $O/bench_C5.json
+for n in 2 4 8; do python bench.py --as-rank 0/$n --cpu-seconds 0 --steps 400 2>/dev/null | tail -1 > $O/bench_asrank0of$n.json; done
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 12 --cpu-seconds 0 --verify 0 --isolated 0 > $GRAFT_REPO_ROOT/$O/trace.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --verify 0 --inflight 1 --batch 1 > $GRAFT_REPO_ROOT/$O/trace1.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/pmc_summary.py $O/trace > $O/trace_summary.txt 2>&1; head -4 $O/trace_summary.txt
+python tools/pmc_summary.py $O/trace1 > $O/trace1_summary.txt 2>&1; head -4 $O/trace1_summary.txt
+rm -rf $O/trace $O/trace1 gpurun_out/pmc_r03_*
+python - <<PY
+import json,glob
+for n in sorted(glob.glob("$O/bench_*.json")):
+    j=json.loads(open(n).read().strip().splitlines()[-1])
+    print(n.split("/")[-1], j["value"], j["ms_per_step"], j["verified"], j["roofline"]["frac"], j["roofline"]["kernel_ms"], j["roofline"].get("traffic"), j["config"]["frames_in_flight"])
+PY
