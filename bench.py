@@ -162,6 +162,14 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def default_batch(args, world):
+    """Frames per dispatch when --batch is not given: several samples per pixel already make one dispatch a long launch
+    (the library folds them into it), so such frames go one per dispatch."""
+    if args.spp > 1:
+        return 1
+    return DEFAULT_BATCH.get(world, 4 if world > 8 else 1)
+
+
 def pmc_key(args, width, height, nbuf, batch):
     """What a set of per-launch PMC figures belongs to (tools/pmc_pass.py writes under the same key)."""
     key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (args.size, width, height, args.mode, args.bounces, args.spp, args.pipeline, nbuf)
@@ -250,7 +258,7 @@ def main():
     ctx.set_camera(cam)
     ctx.set_pipeline(args.pipeline)
     nbuf = min(8, max(2 if use_comm else 1, args.inflight))
-    batch = args.batch if args.batch > 0 else DEFAULT_BATCH.get(world if as_rank is None else as_rank[1], 4 if world > 8 else 1)
+    batch = args.batch if args.batch > 0 else default_batch(args, world if as_rank is None else as_rank[1])
     waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
     if args.pipeline == 1:
         ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and

@@ -47,7 +47,9 @@ struct PersistArgs {
   int tiles_per_band;
   int rows_per_band;   // tile rows per XCD band (SVO_BAND_COLMAJOR)
   int reverse;         // walk the columns right to left (every other launch)
-  int sample;
+  int sample;        // sample index of this launch (one launch per sample), 0 when the launch carries all samples
+  int fold;          // samples per pixel carried by this launch (see persist_launch); 1 = one launch per sample
+  int group;         // fold > 1: tiles per group of a band's walk (sample by sample inside a group)
   int thresh_num;    // a round starts once active lanes <= thresh_num/16 of those active at its start
 };
 
@@ -57,7 +59,10 @@ __device__ __forceinline__ uint32_t xcc_id() {
   return x & 7u;
 }
 
-__device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix, int px, int py, V3 col, float depth) {
+// `sk`: sample index (bits 0..15) and frame of the batch (bits 16..23) of this path when the launch carries all samples of
+// its pixels (a.fold > 1), else 0
+__device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix, uint32_t sk, int px, int py, V3 col, float depth) {
+  const uint32_t smp = sk & 0xffffu;
 #ifdef SVO_NO_STORES  // timing experiment only: keep the values alive, skip the stores
   asm volatile("" ::"v"(col.x), "v"(col.y), "v"(col.z), "v"(depth), "v"(pix));
   return;
@@ -65,12 +70,20 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
   if (a.f.spp <= 1 && !a.f.progressive) {   // the live shader's case: straight to rgba8
     if (px < 10 && py < 10) col = a.f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
     a.color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
+  } else if (a.fold > 1) {
+    // every sample in a slot of its own, [frame][tile][sample][channel][pixel of the tile]: the 64 values of a tile's
+    // sample and channel share two cache lines, and the kernel that adds the samples up in order reads them coalesced
+    const int ry = py - a.f.y0;
+    const uint32_t ty = a.f.row_step == 1 ? (uint32_t)(ry >> 3) : (uint32_t)(ry >> 3) / (uint32_t)a.f.row_step;
+    const uint32_t tile = ty * (uint32_t)a.f.tiles_x + (uint32_t)(px >> 3), l = (uint32_t)(((ry & 7) << 3) | (px & 7));
+    float *p = a.facc + (((size_t)(sk >> 16) * (size_t)a.f.ntiles + tile) * (size_t)a.fold + smp) * 192 + l;
+    p[0] = col.x; p[64] = col.y; p[128] = col.z;
   } else {   // several samples and / or cross-frame accumulation: float sums, finished by persist_resolve_kernel
     float *fx = a.facc + pix, *fy = a.facc + a.npix + pix, *fz = a.facc + 2 * a.npix + pix;
     if (a.sample == 0) { *fx = 0.0f + col.x; *fy = 0.0f + col.y; *fz = 0.0f + col.z; }
     else { *fx = *fx + col.x; *fy = *fy + col.y; *fz = *fz + col.z; }
   }
-  if (a.sample == 0) a.depth[pix] = depth;
+  if (a.sample == 0 && smp == 0u) a.depth[pix] = depth;
 }
 
 // SVO_ASM_LOOP=1 (default): the trips run in trav_loop() (svo_travloop.h, gfx950 assembly);
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 
   SVO_TRAV_T t;
   int status = ST_IDLE;
-  uint32_t pix = 0, seg = 0;
+  uint32_t pix = 0, seg = 0;   // seg: path segment in the low byte; a.fold > 1: sample index in bits 8..23, frame of the batch above
   int px = 0, py = 0;
   // path state that outlives a cast
   V3 d = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), accum = mk(0.f, 0.f, 0.f), normal = mk(0.f, 0.f, 0.f);
@@ -135,7 +148,8 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     if (status >= ST_HIT) {
       const Cast c = SVO_TRAV_RESULT(t, status);
       status = ST_IDLE;
-      if (seg == 0u && f.write_hits && a.sample == 0) {
+      const uint32_t segn = seg & 0xffu, smp = seg >> 8;   // smp: sample | frame of the batch << 16
+      if (segn == 0u && (smp & 0xffffu) == 0u && f.write_hits && a.sample == 0) {
         uint4 h;
         h.x = c.hit ? c.pointer : 0u;
         h.y = c.hit ? ((c.raw & 0xffffu) | ((c.value & 0xffu) << 16) | ((c.level & 0xffu) << 24)) : 0u;
@@ -144,9 +158,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         a.hits[pix] = h;
       }
       if (kMode == 0) {
-        if (seg == 0u && !c.hit) {
+        if (segn == 0u && !c.hit) {
           const V3 s = sky_colour(d);
-          persist_emit(a, pix, px, py, mk(0.0f + s.x, 0.0f + s.y, 0.0f + s.z), 0.0f);
+          persist_emit(a, pix, smp, px, py, mk(0.0f + s.x, 0.0f + s.y, 0.0f + s.z), 0.0f);
         } else {
           V3 vpos = mk(0.f, 0.f, 0.f);
           if (c.hit) { normal = c.normal; value = c.value; vpos = c.voxel_pos; }
@@ -158,8 +172,8 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             mask = mk(mask.x * mc.x, mask.y * mc.y, mask.z * mc.z);
             const float k = dot3(nd, normal);
             mask = mk(mask.x * k, mask.y * k, mask.z * k);
-            if ((int)seg + 1 >= f.bounces) {
-              persist_emit(a, pix, px, py, accum, depth);
+            if ((int)segn + 1 >= f.bounces) {
+              persist_emit(a, pix, smp, px, py, accum, depth);
             } else {
               d = nd;
               seg++;
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             const float diff = acos_pinned(dot3(nd, sun));
             if (diff < 0.4f) accum = mk(accum.x + mask.x * 7.0f, accum.y + mask.y * 7.0f, accum.z + mask.z * 7.0f);
             accum = mk(accum.x + mask.x * 1.0f, accum.y + mask.y * 1.0f, accum.z + mask.z * 1.0f);
-            persist_emit(a, pix, px, py, accum, 0.0f);
+            persist_emit(a, pix, smp, px, py, accum, 0.0f);
           }
         }
       } else if (kMode == 1) {
@@ -178,9 +192,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         if (c.hit) { const float g = 0.005f * (float)c.iter; col = mk(g, g, g); }
         else if (c.capped) col = mk(0.3f, 0.3f, 0.6f);
         else { const float g = 0.01f * (float)c.iter; col = mk(g, g, g); }
-        persist_emit(a, pix, px, py, col, c.hit ? c.t : 0.0f);
+        persist_emit(a, pix, smp, px, py, col, c.hit ? c.t : 0.0f);
       } else if (kMode == 2) {
-        if (seg == 0u) {
+        if (segn == 0u) {
           if (c.hit) {
             V3 mc = material_colour(c.value, mk(0.f, 0.f, 0.f));
             const float k = (c.level >= 10u ? dot3(c.normal, sun2) : dot3(mk(0.f, 1.0f, 0.f), sun2)) * 0.1f;
@@ -194,10 +208,10 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             mc.z = lb * mc.z + (1.0f - lb) * 1.0f;
             mask = mc;
             depth = c.t;
-            seg = 1u;
+            seg = (seg & ~0xffu) | 1u;
             status = SVO_TRAV_INIT(root, t, c.voxel_pos, sun2, false);
           } else {
-            persist_emit(a, pix, px, py, sky_colour(d), 0.0f);
+            persist_emit(a, pix, smp, px, py, sky_colour(d), 0.0f);
           }
         } else {
           V3 mc = mask;
@@ -207,14 +221,14 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             const float pen = (0.05f * (float)c.iter) / 100.0f;
             mc = mk(mc.x - pen, mc.y - pen, mc.z - pen);
           }
-          persist_emit(a, pix, px, py, mc, depth);
+          persist_emit(a, pix, smp, px, py, mc, depth);
         }
       } else if (kMode == 3) {
-        if (c.hit) persist_emit(a, pix, px, py, mk(c.normal.x * 0.5f + 0.5f, c.normal.y * 0.5f + 0.5f,
+        if (c.hit) persist_emit(a, pix, smp, px, py, mk(c.normal.x * 0.5f + 0.5f, c.normal.y * 0.5f + 0.5f,
                                                    c.normal.z * 0.5f + 0.5f), c.t);
-        else persist_emit(a, pix, px, py, mk(0.f, 0.f, 0.f), 0.0f);
+        else persist_emit(a, pix, smp, px, py, mk(0.f, 0.f, 0.f), 0.0f);
       } else {
-        persist_emit(a, pix, px, py, mk(0.f, 0.f, 0.f), 0.0f);
+        persist_emit(a, pix, smp, px, py, mk(0.f, 0.f, 0.f), 0.0f);
       }
     }
 
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         int band_rows = f.tiles_y - first_row;
         band_rows = band_rows < 0 ? 0 : (band_rows > a.rows_per_band ? a.rows_per_band : band_rows);
         const uint32_t band_frame = (uint32_t)(band_rows * f.tiles_x) * 64u;   // pixel slots of the band in one frame
-        const uint32_t band_total = band_frame * (uint32_t)f.batch;              // ... and over the launch's frames
+        const uint32_t band_total = band_frame * (uint32_t)(f.batch * a.fold);   // ... and over the launch's frames x samples
 #else
         const int first_tile = (int)band * a.tiles_per_band;
         int band_tiles = f.ntiles - first_tile;
@@ -253,8 +267,22 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
           const uint32_t l = slot & 63u;
 #if SVO_BAND_COLMAJOR
           // frames of a batch follow one another inside the band: a wave that runs out of frame k goes on with k + 1
-          const uint32_t fi = f.batch > 1 ? slot / band_frame : 0u;
-          const int j = (int)((slot - fi * band_frame) >> 6);
+          // ; the samples of a pixel (a.fold > 1) follow one another tile by tile: tile 0 sample 0, 1, ..., tile 1 sample 0,
+          // ... -- what is in flight at any time are a few tiles' samples, whose primary rays are the same and whose
+          // slots in the sample buffer are neighbours
+          const uint32_t per_frame = band_frame * (uint32_t)a.fold;
+          const uint32_t fi = f.batch > 1 ? slot / per_frame : 0u;
+          const uint32_t q = (slot - fi * per_frame) >> 6;
+          uint32_t si = 0u;
+          int j = (int)q;
+          if (a.fold > 1) {   // groups of a.group tiles: sample 0 of the group's tiles, sample 1 of them, ...
+            const uint32_t tiles = band_frame >> 6, g = q / ((uint32_t)a.group * (uint32_t)a.fold);
+            const uint32_t first = g * (uint32_t)a.group;
+            const uint32_t gsize = tiles - first < (uint32_t)a.group ? tiles - first : (uint32_t)a.group;
+            const uint32_t r = q - first * (uint32_t)a.fold;
+            si = r / gsize;
+            j = (int)(first + r % gsize);
+          }
           int tile_x = j / band_rows;
           const int tile_y = first_row + j % band_rows;
           if (a.reverse) tile_x = f.tiles_x - 1 - tile_x;   // serpentine: this frame ends where the next one starts
@@ -271,14 +299,18 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             pix = (uint32_t)frame_oy(f, tile_y, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
 #endif
             d = primary_direction(f, px, py);
+#if SVO_BAND_COLMAJOR
+            seg = a.fold > 1 ? (si << 8) | (fi << 24) : 0u;
+#else
             seg = 0u;
+#endif
             mask = mk(1.f, 1.f, 1.f);
             accum = mk(0.f, 0.f, 0.f);
             normal = mk(0.f, 0.f, 0.f);
             value = 0u;
             depth = 0.0f;
 #if SVO_BAND_COLMAJOR
-            if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + (int)fi + a.sample));
+            if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + (int)fi + a.sample + (int)si));
 #else
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
 #endif
@@ -319,7 +351,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
       const unsigned long long act = __ballot(status == ST_ACTIVE);
       // cone rays: the secondary segments of a GI path (svotrace.comp:446: coneTrace = i != 0)
       trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold),
-                kMode == 0 ? __ballot(seg != 0u) : 0ull);
+                kMode == 0 ? __ballot((seg & 0xffu) != 0u) : 0ull);
     }
 #else
     for (;;) {
@@ -350,6 +382,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #endif
 }
 
+// a.fold > 1: tiles per group of a band's walk.  1 / 8 / 64 / 512 / all: 4.47 / 4.49 / 4.47 / 4.41 / 4.20 Grays/s at 64
+// samples per pixel (tools/r03_fold2.sh): a group's samples should be in flight together, not a whole band's
+constexpr int kFoldGroup = 8;
 constexpr int kHeadSets = 8;   // counter sets: one per frame in flight (its sample launches follow one another on one
                                // stream and share it), reused round-robin
 constexpr int kFaccSets = 4;   // colour-sum buffers (spp > 1): one per frame, reused round-robin
@@ -364,7 +399,7 @@ struct PersistBuffers {
   float *facc[kFaccSets] = {};
   hipEvent_t facc_done[kFaccSets] = {};
   bool facc_used[kFaccSets] = {};
-  size_t npix = 0;
+  size_t facc_floats = 0;   // floats in each colour-sum buffer
   int blocks = 0;
   int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/sweep8.sh)
   int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
@@ -394,8 +429,22 @@ __global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t 
   const size_t pix = (size_t)blockIdx.z * f.frame_stride +      // frame blockIdx.z of a batch
                      (size_t)frame_oy(f, (int)blockIdx.y >> 3, (int)blockIdx.y & 7) * f.width + x;
   const float inv = 1.0f / (float)f.spp;
-  const V3 col = mk(facc[pix] * inv, facc[npix + pix] * inv, facc[2 * npix + pix] * inv);
-  color[pix] = final_rgba8(f, x, y, col, color + pix);
+  const V3 sum = mk(facc[pix], facc[npix + pix], facc[2 * npix + pix]);
+  color[pix] = final_rgba8(f, x, y, mk(sum.x * inv, sum.y * inv, sum.z * inv), color + pix);
+}
+
+// The same for a launch that left every sample in a slot of its own (persist_emit, a.fold > 1): one workgroup per tile;
+// the samples are added in sample order, the order in which one launch per sample adds them: ((0 + s0) + s1) + ...
+__global__ __launch_bounds__(64) void persist_resolve_tiles_kernel(const Frame f, const float *facc, int fold, uint32_t *color) {
+  const uint32_t l = threadIdx.x, tx = blockIdx.x, ty = blockIdx.y, k = blockIdx.z;
+  const float *p = facc + (((size_t)k * (size_t)f.ntiles + (size_t)ty * f.tiles_x + tx) * (size_t)fold) * 192 + l;
+  V3 sum = mk(0.0f + p[0], 0.0f + p[64], 0.0f + p[128]);
+  for (int i = 1; i < fold; i++) sum = mk(sum.x + p[192 * i], sum.y + p[192 * i + 64], sum.z + p[192 * i + 128]);
+  const int x = (int)(tx * 8u + (l & 7u)), y = frame_gy(f, (int)ty, (int)(l >> 3));
+  if (x >= f.width || y >= f.y1 || y >= f.height) return;
+  const size_t pix = (size_t)k * f.frame_stride + (size_t)frame_oy(f, (int)ty, (int)(l >> 3)) * f.width + x;
+  const float inv = 1.0f / (float)f.spp;
+  color[pix] = final_rgba8(f, x, y, mk(sum.x * inv, sum.y * inv, sum.z * inv), color + pix);
 }
 
 // `out_npix` = elements of the output images: W*H, or more when packed stripes overhang the frame (caller-owned
@@ -431,34 +480,51 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   float *facc = nullptr;
   const unsigned frame_no = b.frames++;
   int fset = 0;
+  // All samples of a frame in ONE launch when their slots fit (3 floats per pixel and sample, kFaccSets times): the
+  // launch's bands hold the frame's samples one after the other like the frames of a batch, a wave goes from sample to
+  // sample without a tail, and the sums cost one store per sample instead of a read-modify-write.  Otherwise one launch
+  // per sample.  Same bytes either way (tests/test_gpu_inflight.py).
+  int fold = 1;
+  unsigned long long slots = 0;
+  if (spp > 1 && f.bounces <= 255 && SVO_BAND_COLMAJOR) {
+    slots = 192ull * (unsigned long long)spp * (unsigned long long)f.ntiles * (f.batch > 1 ? f.batch : 1);
+    const unsigned long long bytes = slots * sizeof(float);
+    static const unsigned long long budget = getenv("SVO_FOLD_BYTES") ? strtoull(getenv("SVO_FOLD_BYTES"), nullptr, 10) : (4ull << 30);
+    if (bytes <= budget && f.batch <= 255 && spp < 65536 && (long long)f.ntiles * (f.batch > 1 ? f.batch : 1) * spp < (1ll << 25)) fold = spp;
+  }
   if (resolve) {
-    if (b.npix < npix) {   // grow: nothing may still be summing into the old planes
+    const size_t need = fold > 1 ? (size_t)slots : 3 * npix;   // floats per buffer
+    if (b.facc_floats < need) {   // grow: nothing may still be summing into the old buffers
       if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
       for (int i = 0; i < kFaccSets; i++) {
         if (b.facc[i]) (void)hipFree(b.facc[i]);
         b.facc[i] = nullptr;
         b.facc_used[i] = false;
-        if ((e = hipMalloc((void **)&b.facc[i], npix * 3 * sizeof(float))) != hipSuccess) return (int)e;
       }
-      b.npix = npix;
+      b.facc_floats = 0;
+      for (int i = 0; i < kFaccSets; i++)
+        if ((e = hipMalloc((void **)&b.facc[i], need * sizeof(float))) != hipSuccess) return (int)e;
+      b.facc_floats = need;
     }
     fset = (int)(frame_no % kFaccSets);
     facc = b.facc[fset];
     if (b.facc_used[fset] && (e = hipStreamWaitEvent(stream, b.facc_done[fset], 0)) != hipSuccess) return (int)e;
   }
   PersistArgs a;
-  a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = facc; a.npix = b.npix;
+  a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = facc; a.npix = npix;
   a.tiles_per_band = (f.ntiles + 7) / 8;
   a.rows_per_band = (f.tiles_y + 7) / 8;
   a.thresh_num = b.thresh_num;
-  const long long work = (long long)f.ntiles * (f.batch > 1 ? f.batch : 1);
+  a.fold = fold;
+  a.group = kFoldGroup;
+  const long long work = (long long)f.ntiles * (f.batch > 1 ? f.batch : 1) * fold;
   const int blocks = work < (long long)b.blocks ? (int)work : b.blocks;
   // a ring of counter sets: frames may be in flight on different streams at the same time.  A frame's sample launches
   // are ordered by its stream, so they share the frame's set; only another frame's re-use waits (for the event)
   const int hset = (int)(frame_no % kHeadSets);
   a.heads = b.heads + (size_t)hset * kHeadWords;
   if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
-  for (int s = 0; s < spp; s++) {
+  for (int s = 0; s < (fold > 1 ? 1 : spp); s++) {
     a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;
     if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
@@ -474,8 +540,13 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   if ((e = hipEventRecord(b.head_done[hset], stream)) != hipSuccess) return (int)e;
   b.head_used[hset] = true;
   if (resolve) {
-    dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8), (unsigned)(f.batch > 1 ? f.batch : 1));
-    hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, facc, b.npix, color);
+    if (fold > 1) {
+      dim3 grid((unsigned)f.tiles_x, (unsigned)f.tiles_y, (unsigned)(f.batch > 1 ? f.batch : 1));
+      hipLaunchKernelGGL(persist_resolve_tiles_kernel, grid, dim3(64), 0, stream, f, facc, fold, color);
+    } else {
+      dim3 grid((unsigned)((f.width + 255) / 256), (unsigned)(f.tiles_y * 8), (unsigned)(f.batch > 1 ? f.batch : 1));
+      hipLaunchKernelGGL(persist_resolve_kernel, grid, dim3(256), 0, stream, f, facc, npix, color);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     if ((e = hipEventRecord(b.facc_done[fset], stream)) != hipSuccess) return (int)e;
     b.facc_used[fset] = true;

@@ -411,3 +411,47 @@ def test_batched_dispatch_equals_one_dispatch_per_frame(ctx, pipeline):
         ctx.set_batch(1, 0)
         ctx.bind_outputs(None, None, None)
         ctx.set_tuning(0, 0)
+
+
+_ONE_LAUNCH_PER_SAMPLE = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import svo_raytracer_amd.scene as scene
+from svo_raytracer_amd import hiplib
+from svo_raytracer_amd.cameras import CAMERAS
+pool, _ = scene.build_scene(128)
+ctx = hiplib.HipContext(0)
+ctx.set_pipeline(1)
+out = {}
+for i, (w, h, spp, bounces, mirror, frame) in enumerate([(200, 120, 5, 3, 0, 4), (64, 37, 16, 2, 0b110, 9), (333, 50, 2, 2, 0, 2)]):
+    r = ctx.render(pool if i == 0 else None, w, h, CAMERAS["K1"], frame, 0, bounces=bounces, mirror_mask=mirror, spp=spp)
+    out["rgba%d" % i] = r["rgba"]; out["depth%d" % i] = r["depth"]; out["hits%d" % i] = r["hits"].view(np.uint8)
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_all_samples_in_one_launch_equal_one_launch_per_sample(ctx, tmp_path):
+    """spp > 1 on the persistent pipeline: one launch carries every sample of the frame (each in a slot of its own, added
+    in sample order afterwards); SVO_FOLD_BYTES=0 (a child process) forces the older one-launch-per-sample path with its
+    running sums.  Same bytes, and the oracle's."""
+    import os
+    import subprocess
+    import sys
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd.cameras import CAMERAS
+    from oracle import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "per_sample.npz")
+    env = dict(os.environ, SVO_FOLD_BYTES="0")
+    subprocess.run([sys.executable, "-c", _ONE_LAUNCH_PER_SAMPLE, root, out], check=True, env=env, timeout=600)
+    z = np.load(out)
+    pool, _ = scene.build_scene(128)
+    ctx.set_pipeline(1)
+    for i, (w, h, spp, bounces, mirror, frame) in enumerate([(200, 120, 5, 3, 0, 4), (64, 37, 16, 2, 0b110, 9), (333, 50, 2, 2, 0, 2)]):
+        got = ctx.render(pool if i == 0 else None, w, h, CAMERAS["K1"], frame, 0, bounces=bounces, mirror_mask=mirror, spp=spp)
+        assert np.array_equal(got["rgba"], z["rgba%d" % i]), i
+        assert np.array_equal(got["depth"].view(np.uint32), z["depth%d" % i].view(np.uint32)), i
+        assert got["hits"].view(np.uint8).tobytes() == z["hits%d" % i].tobytes(), i
+        ref = oracle.render(pool, w, h, CAMERAS["K1"], frame, 0, bounces=bounces, mirror_mask=mirror, spp=spp)
+        assert np.array_equal(got["rgba"], ref["rgba"]), i
+        assert np.array_equal(got["depth"].view(np.uint32), ref["depth"].view(np.uint32)), i

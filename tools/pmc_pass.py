@@ -40,7 +40,7 @@ def main():
     import bench
     a = bench.parse(bench_args)
     nbuf = min(8, max(1, a.inflight))
-    batch = a.batch if a.batch > 0 else bench.DEFAULT_BATCH.get(1, 1)
+    batch = a.batch if a.batch > 0 else bench.default_batch(a, 1)
     key = bench.pmc_key(a, a.width, a.height, nbuf, batch)
     out_root = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, key))
     os.makedirs(out_root, exist_ok=True)
