@@ -123,7 +123,10 @@ int svo_set_camera(svo_ctx *ctx, const float pos[3], const float l1[3], const fl
  * coarse pass that finds, per 4x4 pixel block, a distance before which none of its rays can meet a voxel, and primary
  * rays start their walk there.  The reference's own coarse pass (svobeam.comp) is dormant and inconsistent; here the
  * feature is exact: colour, depth and the hit records' pointer / value / normal / level / t are the same bytes as with
- * use_beam = 0, only the records' iteration counts drop (renderMode 1 displays them, so its colours change). */
+ * use_beam = 0, only the records' iteration counts drop (renderMode 1 displays them, so its colours change).
+ * spp > 1 on pipeline 1: one launch renders every sample of the frame into slots of its own (768 B per pixel at 64 spp,
+ * four such buffers for frames in flight) and a second kernel adds them up in sample order; when a buffer would exceed
+ * 4 GB (environment SVO_FOLD_BYTES overrides) the samples are one launch each with running sums.  Same bytes. */
 int svo_set_params(svo_ctx *ctx, int frame_number, int render_mode, int buffer_end, int use_beam, int bounces,
                    uint32_t mirror_mask, int spp);
 /* replaces the image allocations: rgba8 WxH on unit 0, r32f WxH on unit 1 (Main.java:66-78) */

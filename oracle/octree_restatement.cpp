@@ -26,6 +26,14 @@ using svo::host::Octree;
 
 // ---------------------------------------------------------------------------------------------
 // sdf/SignedDistanceField.java, Sphere.java, Box.java -- integer SDFs of the edit brush.
+// Java's (int) of a double (JLS 5.1.3): NaN -> 0, out of range -> saturated; C++ leaves both undefined
+static inline int java_d2i(double v) {
+  if (v != v) return 0;
+  if (v >= 2147483647.0) return 2147483647;
+  if (v <= -2147483648.0) return -2147483647 - 1;
+  return (int)v;
+}
+
 struct SignedDistanceField {
   int origin[3] = {0, 0, 0}, min[3] = {0, 0, 0}, max[3] = {0, 0, 0};
   virtual ~SignedDistanceField() {}
@@ -36,7 +44,7 @@ struct SignedDistanceField {
     for (int i = 0; i < 3; i++) d[i] = faceOutwards ? pos[i] - origin[i] : origin[i] - pos[i];
     const double len = std::sqrt(std::pow((double)d[0], 2) + std::pow((double)d[1], 2) + std::pow((double)d[2], 2));
     int n[3];
-    for (int i = 0; i < 3; i++) n[i] = (int)(((double)d[i] / len) * 9) / 2 + 5;
+    for (int i = 0; i < 3; i++) n[i] = java_d2i(((double)d[i] / len) * 9) / 2 + 5;   // pos == origin: NaN -> 0 -> digit 5
     return (uint16_t)(int16_t)(n[0] + n[1] * 10 + n[2] * 100);
   }
 };

@@ -14,6 +14,9 @@ python bench.py --config C2 --cpu-seconds 0 2>/dev/null | tail -1 > $O/bench_C2.
 python bench.py --config C4 --cpu-seconds 0 --steps 60 2>/dev/null | tail -1 > $O/bench_C4.json
 python bench.py --config C5 --cpu-seconds 0 --steps 6 --warmup 2 2>/dev/null | tail -1 > $O/bench_C5.json
 for n in 2 4 8; do python bench.py --as-rank 0/$n --cpu-seconds 0 --steps 400 2>/dev/null | tail -1 > $O/bench_asrank0of$n.json; done
+python bench.py --config C4 --as-rank 0/8 --cpu-seconds 0 --steps 120 2>/dev/null | tail -1 > $O/bench_C4_asrank0of8.json
+python bench.py --config C5 --as-rank 0/8 --cpu-seconds 0 --steps 12 --warmup 3 2>/dev/null | tail -1 > $O/bench_C5_asrank0of8.json
+python tests/config_table.py > $O/config_table.md 2>&1; cat $O/config_table.md
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 12 --cpu-seconds 0 --verify 0 --isolated 0 > $GRAFT_REPO_ROOT/$O/trace.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --verify 0 --inflight 1 --batch 1 > $GRAFT_REPO_ROOT/$O/trace1.log 2>&1
