@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
   unsigned long long st_round = 0, st_trav = 0, st_nround = 0, st_ntrip = 0, st_shade = 0, st_load = 0, st_t0 = __builtin_readcyclecounter();
   const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device
   unsigned long long st_dry = 0;
+  uint32_t st_mix[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // trips / lanes, by section (trav_loop)
 #endif
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
@@ -351,7 +352,11 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
       const unsigned long long act = __ballot(status == ST_ACTIVE);
       // cone rays: the secondary segments of a GI path (svotrace.comp:446: coneTrace = i != 0)
       trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold),
-                kMode == 0 ? __ballot((seg & 0xffu) != 0u) : 0ull);
+                kMode == 0 ? __ballot((seg & 0xffu) != 0u) : 0ull
+#ifdef SVO_STAMPS
+                , st_mix
+#endif
+                );
     }
 #else
     for (;;) {
@@ -377,6 +382,9 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     const unsigned long long st_end = __builtin_amdgcn_s_memrealtime();
     atomicMax(dbg + 6, ~st_begin); atomicMax(dbg + 7, ~st_dry); atomicMax(dbg + 8, st_dry); atomicMax(dbg + 9, st_end);
     atomicAdd(dbg + 10, st_end - st_begin); atomicAdd(dbg + 11, st_dry - st_begin);
+    for (int i = 0; i < 8; i += 2)   // dbg[12..15]: lanes << 32 | trips, for the whole trip / descend / advance / pop
+      atomicAdd(dbg + 12 + i / 2, ((unsigned long long)st_mix[i + 1] << 32) + st_mix[i]);
+
     atomicAdd(dbg + 0, st_round); atomicAdd(dbg + 1, st_trav); atomicAdd(dbg + 2, st_nround); atomicAdd(dbg + 3, st_ntrip); atomicAdd(dbg + 4, st_shade); atomicAdd(dbg + 5, st_load);
   }
 #endif

@@ -182,22 +182,41 @@ __device__ __forceinline__ uint32_t lds_offset(T *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) T *)p;
 }
 
+// SVO_STAMPS builds count, per wave: trips, the trips in which the descend / advance / pop sections ran, and the lanes
+// that were active in the trip and in each section (eight scalar counters, added up by the kernel at its end)
+#ifdef SVO_STAMPS
+#define SVO_COUNT(slot, lanes, mask)                     \
+  "s_bcnt1_i32_b64 %[cnt], " mask "\n\t"                \
+  "s_add_u32 %[" slot "], %[" slot "], 1\n\t"             \
+  "s_add_u32 %[" lanes "], %[" lanes "], %[cnt]\n\t"
+#else
+#define SVO_COUNT(slot, lanes, mask)
+#endif
+
 // Run trips until at most `threshold` lanes of `act` (the lanes with status == ST_ACTIVE) are still traversing.
 // Lanes that stop get their status (ST_HIT / ST_MISS / ST_CAPPED); r.rlo/r.rhi are then the hit record.
 // `cone_lanes`: the lanes whose ray is a cone (secondary) ray -- they drop to LOD 11 once t_min > 0.05 (svotrace.comp:275-277).
 __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, const uint32_t lane, TravRegs &r,
                                           int &status, unsigned long long act, const int threshold,
-                                          const unsigned long long cone_lanes) {
+                                          const unsigned long long cone_lanes, uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
   const uint32_t lds2 = lds_offset(&stk.mk[lane]);
   unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh;
   int cnt;
+#ifdef SVO_STAMPS
+#define SVO_RFL(i) (uint32_t) __builtin_amdgcn_readfirstlane((int)mix[i])
+  uint32_t c0 = SVO_RFL(0), c1 = SVO_RFL(1), c2 = SVO_RFL(2), c3 = SVO_RFL(3), c4 = SVO_RFL(4), c5 = SVO_RFL(5), c6 = SVO_RFL(6), c7 = SVO_RFL(7);
+#undef SVO_RFL
+#else
+  (void)mix;
+#endif
   uint32_t t0, t1, t2, t3;
   float tcx, tcm;
   asm volatile(
       "s_mov_b64 %[sv], exec\n"
       "Ltrip%=:\n\t"
       "s_mov_b64 exec, %[act]\n\t"
+      SVO_COUNT("c0", "c1", "exec")
       // ---- child slot, iteration cap (svotrace.comp:263-266)
       // the child index is not carried: it is the bit `scale` of the three position components (a cell's origin is a
       // multiple of its size), so the descend / pop sections need not rebuild it
@@ -276,6 +295,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       // ---- DESCEND (svotrace.comp:291-327)
       "s_mov_b64 exec, %[sd]\n\t"
       "s_cbranch_execz LnoD%=\n\t"
+      SVO_COUNT("c2", "c3", "exec")
       "v_cmp_lt_f32 vcc, %[tcm], %[h]\n\t"                    // tc_max < h: PUSH
       "v_mul_f32 v72, 0.5, v72\n\t"                       // half
       "v_add_u32 %[t0], -11, %[scale]\n\t"
@@ -308,6 +328,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       // ---- ADVANCE (svotrace.comp:329-339)
       "s_mov_b64 exec, %[sa]\n\t"
       "s_cbranch_execz LnoA%=\n\t"
+      SVO_COUNT("c4", "c5", "exec")
       "v_mov_b32 %[tmin], %[tcm]\n\t"                            // t_min = tc_max
       "v_sub_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[68:69], v[68:69], v[92:93] neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -315,6 +336,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "v_cmp_ne_u32 vcc, 0, %[t2]\n\t"                      // left the parent: POP
       "s_mov_b64 exec, vcc\n\t"
       "s_cbranch_execz LnoA%=\n\t"
+      SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
       "v_add_f32 %[t0], %[px], %[t0]\n\t"                       // position before the step (exact)
       "v_pk_add_f32 v[92:93], v[68:69], v[92:93]\n\t"
@@ -368,10 +390,16 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
         "=&{v88}"(r.rlo), "=&{v89}"(r.rhi), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
         [t3] "=&v"(t3), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd),
         [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh), [cnt] "=&s"(cnt)
+#ifdef SVO_STAMPS
+        , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
+#endif
       : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
         [lds8] "v"(lds8), [lds2] "v"(lds2), [rs] "s"(pool.rsrc), [k5555] "s"(0x5555u), [selcp] "s"(0x01020304u),
         [selmask] "s"(0x0c0c0102u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
       : "vcc", "scc", "memory", "v73", "v86", "v87", "v90", "v92", "v93");
+#ifdef SVO_STAMPS
+  mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7;
+#endif
 }
 
 }  // namespace svo

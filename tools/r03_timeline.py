@@ -25,5 +25,11 @@ for wpc in (8, 10, 14, 20):
         begin = M - d[6]
         first_dry = M - d[7]
         us = lambda t: (t - begin) / 100.0
+        mix = [(d[12 + i] & 0xffffffff, d[12 + i] >> 32) for i in range(4)]
+        if frame == 2 and mix[0][0]:
+            t = mix[0][0]
+            print("  per wave-trip: active lanes %.1f | descend section in %.1f %% of trips with %.1f lanes | advance %.1f %% with %.1f | pop %.1f %% with %.1f"
+                  % (mix[0][1] / t, 100.0 * mix[1][0] / t, mix[1][1] / max(1, mix[1][0]), 100.0 * mix[2][0] / t, mix[2][1] / max(1, mix[2][0]),
+                     100.0 * mix[3][0] / t, mix[3][1] / max(1, mix[3][0])))
         print("waves/CU %2d frame %d: %.3f ms by events | first wave out of work at %.0f us, last at %.0f us (mean %.0f), last wave ends %.0f us (mean end %.0f)"
               % (wpc, frame, ms[-1], us(first_dry), us(d[8]), d[11] / nw / 100.0, us(d[9]), d[10] / nw / 100.0))
