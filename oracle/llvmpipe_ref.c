@@ -16,6 +16,8 @@
  * Usage:  llvmpipe_ref <shader.comp>  < jobfile
  * Job file (one command per line):
  *   pool <file>                 raw SVO byte pool (T1 layout)
+ *   pad <bytes>                 zero bytes behind the pools that follow (the reference's buffer is far larger
+ *                               than the bytes in use); default 64
  *   size <W> <H>
  *   cam <15 hex u32>            bit patterns of pos,l1,l2,r1,r2 floats
  *   frame <n>   mode <m>
@@ -307,7 +309,7 @@ int main(int argc, char **argv) {
   GLuint tex[3] = {0, 0, 0};
   float cam[15] = {1.5f, 1.5f, 2.0f, -1.6f, -0.9f, -1, -1.6f, 0.9f, -1, 1.6f, -0.9f, -1, 1.6f, 0.9f, -1};
   GLuint ssbo = 0;
-  size_t pool_len = 0;
+  size_t pool_len = 0, pad_bytes = 0;
   char line[8192];
   glPixelStorei(GL_PACK_ALIGNMENT, 1);
   while (fgets(line, sizeof line, stdin)) {
@@ -318,7 +320,7 @@ int main(int argc, char **argv) {
       char *pool = read_file(arg, &pool_len);
       /* the reference over-allocates its buffer (Octree.java:63-67); pad with zeros so
          the shader's dword reads past the last record stay inside the SSBO */
-      size_t padded = ((pool_len + 3) & ~(size_t)3) + 64;
+      size_t padded = ((pool_len + 3) & ~(size_t)3) + 64 + pad_bytes;
       char *buf = calloc(1, padded);
       memcpy(buf, pool, pool_len);
       if (ssbo) glDeleteBuffers(1, &ssbo);
@@ -327,6 +329,11 @@ int main(int argc, char **argv) {
       glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)padded, buf, GL_DYNAMIC_DRAW);
       glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 7, ssbo);
       free(buf); free(pool);
+    } else if (!strcmp(cmd, "pad")) {          /* zero bytes behind the pools that follow: the reference's buffer is far
+                                                  larger than the bytes in use (Octree.java:63-67, Renderer.java:101-113) */
+      unsigned long v = 0;
+      sscanf(line, "%*s %lu", &v);
+      pad_bytes = (size_t)v;
     } else if (!strcmp(cmd, "size")) {
       sscanf(line, "%*s %d %d", &W, &H);
     } else if (!strcmp(cmd, "cam")) {

@@ -527,7 +527,9 @@ static vec3 trace(ctx_t *c, const svo_oracle_params *prm, float beamDist, float 
     record_hit(hit, &res, intersect);
     if (intersect) {
       *depth = res.t;
-      vec3 matcolor = v3(0, 0, 0); /* pin P8 */
+      /* pin P8: the shader leaves matcolor uninitialised for other values (svotrace.comp:577-586); llvmpipe resolves the
+         undefined value to material 1's colour (tests/golden/fuzz_golden.npz: values 4 and 127) */
+      vec3 matcolor = v3(0.84f, 0.86f, 0.78f);
       if (res.value == 1) matcolor = v3(0.84f, 0.86f, 0.78f);
       if (res.value == 2) matcolor = v3(0.57f, 0.5f, 0.31f);
       if (res.value == 3) matcolor = v3(0.37f, 0.43f, 0.27f);

@@ -349,6 +349,9 @@ __device__ __forceinline__ Cast cast_ray(const Pool &pool, WaveStack &stk, const
 }
 
 // material colour table of svotrace.comp:514-522 / :577-586
+// renderMode 2 leaves its colour variable unset for values other than 1..3 (svotrace.comp:577-586); the reference under
+// llvmpipe resolves the undefined value to material 1's colour (tests/golden/fuzz_golden.npz: values 4 and 127)
+#define kMode2OtherMaterial mk(0.84f, 0.86f, 0.78f)
 __device__ __forceinline__ V3 material_colour(uint32_t value, V3 other) {
   if (value == 1u) return mk(0.84f, 0.86f, 0.78f);
   if (value == 2u) return mk(0.57f, 0.5f, 0.31f);

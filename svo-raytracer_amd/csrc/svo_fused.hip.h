@@ -127,7 +127,7 @@ __device__ __forceinline__ void trace_sample(const Pool &pool, WaveStack &stk, u
     if (first) record_first(ps, c);
     if (c.hit) {
       depth = c.t;
-      V3 mc = material_colour(c.value, mk(0.f, 0.f, 0.f));
+      V3 mc = material_colour(c.value, kMode2OtherMaterial);
       const V3 sun = normalize3(mk(0.5f, 0.5f, 0.5f));
       const float k = (c.level >= 10u ? dot3(c.normal, sun) : dot3(mk(0.f, 1.0f, 0.f), sun)) * 0.1f;
       mc = mk(mc.x + k, mc.y + k, mc.z + k);

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
         h.y = c.hit ? ((c.raw & 0xffffu) | ((c.value & 0xffu) << 16) | ((c.level & 0xffu) << 24)) : 0u;
         h.z = c.iter;
         h.w = c.hit ? __float_as_uint(c.t) : 0u;
+        if (kMode == 4) h = make_uint4(0u, 0u, 0u, 0u);   // trace() casts nothing in modes >= 4 (svotrace.comp:643-646)
         a.hits[pix] = h;
       }
       if (kMode == 0) {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
       } else if (kMode == 2) {
         if (segn == 0u) {
           if (c.hit) {
-            V3 mc = material_colour(c.value, mk(0.f, 0.f, 0.f));
+            V3 mc = material_colour(c.value, kMode2OtherMaterial);
             const float k = (c.level >= 10u ? dot3(c.normal, sun2) : dot3(mk(0.f, 1.0f, 0.f), sun2)) * 0.1f;
             mc = mk(mc.x + k, mc.y + k, mc.z + k);
             const float dist = c.t + 0.0f;
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
 #endif
             status = SVO_TRAV_INIT(root, t, cam_o, d, false, beam_start(f, px, py));
+            if (kMode == 4) status = ST_MISS;   // no cast: straight to the (black) pixel
           }
         }
         if (base + n >= band_total) {  // this band is used up: move on (work stealing)

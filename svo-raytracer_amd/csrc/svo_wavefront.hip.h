@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const WfArgs a) {
       h.y = c.hit ? ((c.raw & 0xffffu) | ((c.value & 0xffu) << 16) | ((c.level & 0xffu) << 24)) : 0u;
       h.z = c.iter;
       h.w = c.hit ? __float_as_uint(c.t) : 0u;
+      if (kMode == 4) h = make_uint4(0u, 0u, 0u, 0u);   // trace() casts nothing in modes >= 4 (svotrace.comp:643-646)
       a.hits[pix] = h;
     }
     if (kMode == 0) {
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const WfArgs a) {
       const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
       if (kPrimary) {
         if (c.hit) {
-          V3 mc = material_colour(c.value, mk(0.f, 0.f, 0.f));
+          V3 mc = material_colour(c.value, kMode2OtherMaterial);
           const float k = (c.level >= 10u ? dot3(c.normal, sun2) : dot3(mk(0.f, 1.0f, 0.f), sun2)) * 0.1f;
           mc = mk(mc.x + k, mc.y + k, mc.z + k);
           const float dist = c.t + 0.0f;

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Golden vectors for pools no builder produces, again from the REFERENCE shader itself under Mesa llvmpipe
+(oracle/_ref/llvmpipe_ref; the shader is read from /root/reference at run time, never copied):
+
+  * random structurally valid pools (tests/fuzzpool.py): arbitrary tag mixes, empty interior nodes, interior nodes
+    without a child block, any 16-bit 'normal', tag-2 nodes with stale bytes, DELETE_VALUE, materials the shader has no
+    colour for (renderMode 2 then reads a variable it never set); renderModes 4, 5 and -1 on two of them;
+  * the same pools with child pointers re-aimed: backwards (cycles: the cast runs into the iteration cap), into the
+    middle of other records (any alignment), and past the last byte in use -- inside the zero bytes the reference's
+    buffer always has behind memOffset (its byte[] is far larger than the tree; the harness is told to keep 1 MiB,
+    and only such pointers are generated: what GL does beyond a buffer's end is not the reference's behaviour).
+
+Runs only in the build container.  Output: tests/golden/fuzz_golden.npz (data only).
+
+    python tests/golden/make_golden_fuzz.py
+"""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import svo_raytracer_amd.scene as scene  # noqa: E402
+from svo_raytracer_amd.cameras import CAMERAS, rot_cam  # noqa: E402
+import fuzzpool  # noqa: E402
+
+SHADER = "/root/reference/src/shaders/svotrace.comp"
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
+OUT = os.path.dirname(os.path.abspath(__file__))
+PAD = 1 << 20
+W, H = 56, 36
+
+
+def interior_offsets(p, limit=4000):
+    out, stack = [], [0]
+    while stack and len(out) < limit:
+        o = stack.pop()
+        cp = int.from_bytes(bytes(p[o + 1:o + 5]), "big", signed=True)
+        if cp == 0:
+            continue
+        out.append(o)
+        mask = (int(p[o + 5]) << 8) | int(p[o + 6])
+        c = o + cp
+        for n in range(8):
+            tag = (mask >> (2 * n)) & 3
+            if tag == 0 and c + 7 <= p.size:
+                stack.append(c)
+            c += {0: 7, 1: 3, 2: 7, 3: 1}[tag]
+    return out
+
+
+def mangled(pool, seed):
+    """child pointers re-aimed; every target stays below len + PAD - 64 (inside the buffer the reference would have)"""
+    rng = np.random.RandomState(7000 + seed)
+    p = pool.copy()
+    inter = interior_offsets(p)
+    for o in rng.choice(inter[1:], size=min(10, len(inter) - 1), replace=False):
+        kind = rng.randint(0, 3)
+        if kind == 0:
+            target = 0                                             # back to the root block: a cycle
+        elif kind == 1:
+            target = int(p.size) + int(rng.randint(0, PAD - 4096))  # zero bytes behind the tree
+        else:
+            target = int(rng.randint(7, p.size))                   # somewhere inside the pool, any alignment
+        p[o + 1:o + 5] = np.frombuffer(int(target - int(o)).to_bytes(4, "big", signed=True), dtype=np.uint8)
+    return p
+
+
+def cases():
+    cams = {"K0": CAMERAS["K0"], "K1": CAMERAS["K1"], "KA": rot_cam((1.45, 1.7, 2.9), -0.35, 0.1), "KB": rot_cam((1.5, 1.5, 1.5), 0.9, 2.0)}
+    pools, cs = {}, []
+    for seed in range(6):
+        base = fuzzpool.random_pool(seed, max_depth=5 + seed % 2, p_interior=0.8, p_empty=0.8)
+        deep = seed % 3 == 2
+        if deep:
+            base = scene.embed_deep(base, 7)       # depth 12-13: LOD cap on bounce rays, Phong branch
+        pools["f%d" % seed] = base
+        pools["m%d" % seed] = mangled(base, seed)
+        for kind in ("f", "m"):
+            for cn, cam in cams.items():
+                cam = cam.copy()
+                if deep:
+                    cam[:3] = (1.0 + (cam[:3].astype(np.float64) - 1.0) / 128).astype(np.float32)
+                for mode in (0, 1, 2, 3):
+                    if kind == "m" and cn in ("K1", "KA") and mode in (1, 3):
+                        continue                   # keep the fixture small
+                    cs.append(("%s%d_%s_m%d" % (kind, seed, cn, mode), "%s%d" % (kind, seed), cam, 2 + seed, mode))
+            if kind == "f" and seed in (0, 3):     # renderMode 4 returns an unset variable, 5.. and negatives fall off the end of trace()
+                for mode in (4, 5, -1):
+                    cs.append(("f%d_K0_m%d" % (seed, mode), "f%d" % seed, cams["K0"].copy(), 2 + seed, mode))
+    return pools, cs
+
+
+def main():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    pools, cs = cases()
+    tmp = tempfile.mkdtemp(prefix="golden_fuzz_")
+    job, cur = ["pad %d" % PAD, "size %d %d" % (W, H)], None
+    for name, pk, cam, frame, mode in cs:
+        if pk != cur:
+            path = os.path.join(tmp, pk + ".bin")
+            pools[pk].tofile(path)
+            job.append("pool " + path)
+            cur = pk
+        hexs = " ".join("%08x" % struct.unpack("<I", struct.pack("<f", float(v)))[0] for v in cam)
+        job += ["cam " + hexs, "frame %d" % frame, "mode %d" % mode, "ptrpatch 0", "render " + os.path.join(tmp, name),
+                "ptrpatch 1", "render " + os.path.join(tmp, name + "_p")]
+    r = subprocess.run([REF_BIN, SHADER], input=("\n".join(job) + "\n").encode(), capture_output=True)
+    sys.stderr.write(r.stderr.decode()[-600:])
+    assert r.returncode == 0
+    out, index = {}, []
+    for name, pk, cam, frame, mode in cs:
+        rgba = np.fromfile(os.path.join(tmp, name + ".rgba"), dtype=np.uint8).reshape(H, W, 4)
+        depth = np.fromfile(os.path.join(tmp, name + ".depth"), dtype=np.uint32).reshape(H, W)
+        rgba_p = np.fromfile(os.path.join(tmp, name + "_p.rgba"), dtype=np.uint8).reshape(H, W, 4)
+        depth_p = np.fromfile(os.path.join(tmp, name + "_p.depth"), dtype=np.uint32).reshape(H, W)
+        ptr = np.fromfile(os.path.join(tmp, name + "_p.ptr"), dtype=np.uint32).reshape(H, W, 4)
+        same = bool((rgba == rgba_p).all() and (depth == depth_p).all())
+        print("%-14s mode %d frame %d hits %5d capped %4d patched==plain %s" %
+              (name, mode, frame, int((ptr[..., 0] != 0).sum()), int(((ptr[..., 3] & 0xffff) > 1500).sum()), same))
+        out[name + "/rgba"] = rgba
+        out[name + "/depth_bits"] = depth
+        out[name + "/first_hit"] = ptr
+        out[name + "/cam"] = np.asarray(cam, dtype=np.float32)
+        out[name + "/meta"] = np.array([W, H, frame, mode, int(same)], dtype=np.int32)
+        index.append(name + ":" + pk)
+    for pk, p in pools.items():
+        out["pool/" + pk] = p
+    out["index"] = np.array(index)
+    path = os.path.join(OUT, "fuzz_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(cs), "cases")
+
+
+if __name__ == "__main__":
+    main()

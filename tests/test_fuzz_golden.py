@@ -1,0 +1,68 @@
+"""Pools no builder produces, under the reference shader itself (tests/golden/fuzz_golden.npz, made by
+tests/golden/make_golden_fuzz.py on Mesa llvmpipe): random tag / value / normal mixes, child pointers that point
+backwards, into the middle of other records and into the zero bytes behind the tree; every render mode, incl. the
+ones trace() has no branch for.  The oracle and the three HIP pipelines against those vectors, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import compare_with_golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_Z = None
+
+
+def _z():
+    global _Z
+    if _Z is None:
+        _Z = np.load(os.path.join(HERE, "golden", "fuzz_golden.npz"))
+    return _Z
+
+
+def _cases():
+    z = np.load(os.path.join(HERE, "golden", "fuzz_golden.npz"))
+    return [tuple(s.split(":")) for s in z["index"]]
+
+
+def _golden(name):
+    z = _z()
+    w, h, frame, mode, same = (int(v) for v in z[name + "/meta"])
+    return dict(w=w, h=h, frame=frame, mode=mode, patched_same=bool(same), cam=z[name + "/cam"], rgba=z[name + "/rgba"],
+                depth_bits=z[name + "/depth_bits"], first_hit=z[name + "/first_hit"])
+
+
+def test_fixture_is_what_the_generator_describes():
+    cases = _cases()
+    assert len(cases) >= 170
+    assert {pk[0] for _, pk in cases} == {"f", "m"}
+    assert {int(_z()[n + "/meta"][3]) for n, _ in cases} >= {0, 1, 2, 3, 4, 5, -1}
+
+
+@pytest.mark.parametrize("name,poolkey", _cases())
+def test_oracle_matches_reference_shader_on_fuzz_pools(name, poolkey):
+    from oracle import oracle
+    g = _golden(name)
+    assert g["patched_same"]
+    res = oracle.render(_z()["pool/" + poolkey], g["w"], g["h"], g["cam"], g["frame"], g["mode"])
+    bad = compare_with_golden(res, g)
+    assert bad == {k: 0 for k in bad}, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("poolkey", sorted({pk for _, pk in _cases()}))
+def test_hip_matches_reference_shader_on_fuzz_pools(poolkey):
+    from svo_raytracer_amd import hiplib
+    ctx = hiplib.HipContext(0)
+    try:
+        pool = _z()["pool/" + poolkey]
+        names = [n for n, pk in _cases() if pk == poolkey]
+        for pipeline in (0, 1, 2):
+            ctx.set_pipeline(pipeline)
+            for i, name in enumerate(names):
+                g = _golden(name)
+                res = ctx.render(pool if i == 0 else None, g["w"], g["h"], g["cam"], g["frame"], g["mode"])
+                bad = compare_with_golden(res, g)
+                assert bad == {k: 0 for k in bad}, (name, pipeline, bad)
+    finally:
+        ctx.close()
