@@ -13,7 +13,7 @@
  *                      6 renderMode, 9 bufferEnd, 11 useBeamOptimization
  *   Renderer.java:118-121  glDispatchCompute + glMemoryBarrier
  *
- * Usage:  llvmpipe_ref <shader.comp>  < jobfile
+ * Usage:  llvmpipe_ref <shader.comp> [raw]  < jobfile      (raw: a probe shader with the same bindings, no patches)
  * Job file (one command per line):
  *   pool <file>                 raw SVO byte pool (T1 layout)
  *   pad <bytes>                 zero bytes behind the pools that follow (the reference's buffer is far larger
@@ -299,11 +299,11 @@ int main(int argc, char **argv) {
   fprintf(stderr, "GL_VERSION %s | %s\n", glGetString(GL_VERSION), glGetString(GL_RENDERER));
 
   char *src = read_file(argv[1], NULL);
-  char *src_patched = apply_ptr_patch(src);
+  /* "raw": a probe shader of our own with the same bindings (tools/probes/), run as it is -- no in-memory patches */
+  const int raw = argc > 2 && !strcmp(argv[2], "raw");
   GLuint prog_plain = build_program(src);
-  GLuint prog_patched = build_program(src_patched);
-  char *src_accum = apply_accum_patch(src, 712, 719);
-  GLuint prog_accum = build_program(src_accum);
+  GLuint prog_patched = raw ? prog_plain : build_program(apply_ptr_patch(src));
+  GLuint prog_accum = raw ? prog_plain : build_program(apply_accum_patch(src, 712, 719));
 
   int W = 256, H = 256, frame = 2, mode = 2, ptrpatch = 0, accum = 0, keep = 0, have_tex = 0, texW = 0, texH = 0;
   GLuint tex[3] = {0, 0, 0};

@@ -113,8 +113,10 @@ static inline int find_msb(uint32_t v) { return v ? 31 - __builtin_clz(v) : -1; 
 static float sincos_core(float x, int want_cos) {
   float ax = fabsf(x);
   float y = ax * 1.27323954473516f;
-  int j = (int)y;
-  j = (j + 1) & ~1;
+  /* the conversion is x86's cvttps2dq: out of range (|x| >= 1.69e9) and NaN give 0x80000000 */
+  uint32_t ju = (y >= 2147483648.0f || y != y) ? 0x80000000u : (uint32_t)(int)y;
+  ju = (ju + 1u) & ~1u;
+  int j = (int)ju;
   y = (float)j;
   float r = fmaf(y, -0.78515625f, ax);
   r = fmaf(y, -2.4187564849853515625e-4f, r);
@@ -142,7 +144,12 @@ static float sincos_core(float x, int want_cos) {
     q = q * z;
     v = fmaf(q, r, r);
   }
-  return neg ? -v : v;
+  v = neg ? -v : v;
+  /* llvmpipe clamps the result to [-1, 1] (visible once the reduced argument is no longer small: |x| > ~6e7);
+     round 2, tools/probes/sin_probe.comp */
+  if (v > 1.0f) v = 1.0f;
+  if (v < -1.0f) v = -1.0f;
+  return v;
 }
 static float gsin(float x) { return sincos_core(x, 0); }
 static float gcos(float x) { return sincos_core(x, 1); }

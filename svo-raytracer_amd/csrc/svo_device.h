@@ -53,8 +53,12 @@ __device__ __forceinline__ bool all_nan(V3 v) { return (v.x != v.x) && (v.y != v
 template <bool kCos>
 __device__ __forceinline__ float sincos_pinned(float x) {
   const float ax = __builtin_fabsf(x);
-  int j = (int)(ax * 1.27323954473516f);
-  j = (j + 1) & ~1;
+  const float yf = ax * 1.27323954473516f;
+  // the conversion is x86's cvttps2dq (llvmpipe's host): out of range (|x| >= 1.69e9) and NaN give 0x80000000, where
+  // v_cvt_i32_f32 would saturate; reachable through frameNumber (svotrace.comp:486 multiplies it by 7.8)
+  uint32_t ju = (yf >= 2147483648.0f || yf != yf) ? 0x80000000u : (uint32_t)(int)yf;
+  ju = (ju + 1u) & ~1u;
+  const int j = (int)ju;
   const float y = (float)j;
   float r = __builtin_fmaf(y, -0.78515625f, ax);
   r = __builtin_fmaf(y, -2.4187564849853515625e-4f, r);
@@ -75,8 +79,13 @@ __device__ __forceinline__ float sincos_pinned(float x) {
   ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
   ps = ps * z;
   ps = __builtin_fmaf(ps, r, r);
-  const float v = cos_poly ? pc : ps;
-  return neg ? -v : v;
+  float v = cos_poly ? pc : ps;
+  v = neg ? -v : v;
+  // llvmpipe clamps the result to [-1, 1]: visible once the reduced argument stops being small (|x| > ~6e7, i.e.
+  // frameNumber beyond 2^23; tools/probes/sin_probe.comp)
+  v = v > 1.0f ? 1.0f : v;
+  v = v < -1.0f ? -1.0f : v;
+  return v;
 }
 __device__ __forceinline__ float acos_pinned(float x) {
   const float ax = __builtin_fabsf(x);

@@ -10,6 +10,9 @@
     buffer always has behind memOffset (its byte[] is far larger than the tree; the harness is told to keep 1 MiB,
     and only such pointers are generated: what GL does beyond a buffer's end is not the reference's behaviour).
 
+  * the terrain scene at frame numbers up to +-2^31, and llvmpipe's sin / cos themselves at such arguments (a probe
+    shader of our own, tools/probes/sin_probe.comp: mode 0 sin, 1 cos of frame + 977 i, 2 sin(12.9898 i + 7.8233 frame)).
+
 Runs only in the build container.  Output: tests/golden/fuzz_golden.npz (data only).
 
     python tests/golden/make_golden_fuzz.py
@@ -93,7 +96,39 @@ def cases():
             if kind == "f" and seed in (0, 3):     # renderMode 4 returns an unset variable, 5.. and negatives fall off the end of trace()
                 for mode in (4, 5, -1):
                     cs.append(("f%d_K0_m%d" % (seed, mode), "f%d" % seed, cams["K0"].copy(), 2 + seed, mode))
+    # frameNumber far beyond the goldens of round 1 (2, 3, 7, 99): svotrace.comp:486 feeds frameNumber * 7.8 to sin();
+    # beyond 2^23 llvmpipe's range reduction breaks down and the clamp of its result shows, beyond 2.7e8 the float -> int
+    # conversion inside it overflows (x86 semantics)
+    pools["s128"] = scene.build_scene(128)[0]
+    for fr in (-5, 1000000, 16777216, 123456789, 300000000, 2147483647, -2147483648):
+        cs.append(("s128_K1_m0_f%d" % fr, "s128", cams["K1"].copy(), fr, 0))
     return pools, cs
+
+
+BIG_FRAMES = (0, -7, 1000000, 8000000, 16777216, 60000000, 100000000, 215000000, 216000000, 1000000000, 2147483647, -2147483648)
+PW, PH = 32, 16
+
+
+def sin_probe(tmp, out):
+    """llvmpipe's sin / cos at large arguments, through a probe shader of our own (tools/probes/sin_probe.comp)"""
+    job = ["size %d %d" % (PW, PH)]
+    for fr in BIG_FRAMES:
+        for m in (0, 1, 2):
+            job += ["frame %d" % fr, "mode %d" % m, "ptrpatch 0", "render " + os.path.join(tmp, "sp%d_%d" % (fr, m))]
+    r = subprocess.run([REF_BIN, os.path.join(ROOT, "tools", "probes", "sin_probe.comp"), "raw"],
+                       input=("\n".join(job) + "\n").encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    idx = np.arange(PW * PH, dtype=np.float32)
+    for fr in BIG_FRAMES:
+        f = np.float32(fr)
+        for m in (0, 1, 2):
+            if m < 2:
+                x = (f + (idx * np.float32(977.0)).astype(np.float32)).astype(np.float32)
+            else:
+                x = ((idx * np.float32(12.9898)).astype(np.float32) + np.float32(f * np.float32(7.8233))).astype(np.float32)
+            out["sinprobe/%d_%d/x" % (fr, m)] = x
+            out["sinprobe/%d_%d/ref_bits" % (fr, m)] = np.fromfile(os.path.join(tmp, "sp%d_%d.depth" % (fr, m)), dtype=np.uint32)
+    out["sinprobe/index"] = np.array(["%d_%d" % (fr, m) for fr in BIG_FRAMES for m in (0, 1, 2)])
 
 
 def main():
@@ -132,6 +167,7 @@ def main():
     for pk, p in pools.items():
         out["pool/" + pk] = p
     out["index"] = np.array(index)
+    sin_probe(tmp, out)
     path = os.path.join(OUT, "fuzz_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(cs), "cases")

@@ -34,8 +34,9 @@ def _golden(name):
 
 def test_fixture_is_what_the_generator_describes():
     cases = _cases()
-    assert len(cases) >= 170
-    assert {pk[0] for _, pk in cases} == {"f", "m"}
+    assert len(cases) >= 180
+    assert {pk[0] for _, pk in cases} == {"f", "m", "s"}
+    assert {int(_z()[n + "/meta"][2]) for n, _ in cases} >= {2147483647, -2147483648, 16777216}
     assert {int(_z()[n + "/meta"][3]) for n, _ in cases} >= {0, 1, 2, 3, 4, 5, -1}
 
 
@@ -66,3 +67,23 @@ def test_hip_matches_reference_shader_on_fuzz_pools(poolkey):
                 assert bad == {k: 0 for k in bad}, (name, pipeline, bad)
     finally:
         ctx.close()
+
+
+def test_oracle_sin_cos_at_large_arguments_are_llvmpipe_s():
+    """sin / cos of arguments up to 1.7e10 (frameNumber * 7.8 at frameNumber = +-2^31): the clamp of the result to [-1, 1]
+    and the x86 float -> int conversion inside the range reduction, recorded from llvmpipe through a probe shader."""
+    import ctypes
+    from oracle import oracle
+    L = oracle.lib()
+    for fn in (L.svo_oracle_sin, L.svo_oracle_cos):
+        fn.restype = ctypes.c_float
+        fn.argtypes = [ctypes.c_float]
+    z = _z()
+    n = 0
+    for key in z["sinprobe/index"]:
+        x, ref = z["sinprobe/%s/x" % key], z["sinprobe/%s/ref_bits" % key]
+        fn = L.svo_oracle_cos if key.endswith("_1") else L.svo_oracle_sin
+        mine = np.array([fn(float(v)) for v in x], dtype=np.float32).view(np.uint32)
+        assert np.array_equal(mine, ref), key
+        n += int((np.abs(ref.view(np.float32)) == 1.0).sum())
+    assert n > 1000   # the clamp is really exercised
