@@ -156,12 +156,14 @@ static float gcos(float x) { return sincos_core(x, 1); }
 static float gacos(float x) {
   float ax = fabsf(x);
   float t = ax * (-0.02363318f) + 0.08132463f;
-  t = ax * t + (-0.2145988f);
+  t = ax * t + (0.785398163f - 1.0f); /* (float)(pi/4) - 1 = -0.21460181 (round 1 had mistyped it as -0.2145988: a 3e-6
+                                         error that only the < 0.4 test of svotrace.comp:540 ever saw; tools/probes/fn_probe.comp) */
   t = ax * t + 1.5707964f;
   return 1.5707964f - gsign(x) * (1.5707964f - sqrtf(1.0f - ax) * t);
 }
 static float gexp2(float y) {
-  y = gmin(y, 129.0f);
+  if (y != y) return y;   /* NaN in, NaN out (the clamps below would otherwise swallow it) */
+  y = gmin(y, 128.0f);
   y = gmax(y, -126.99999f);
   float ip = floorf(y);
   float fp = y - ip;
@@ -170,7 +172,8 @@ static float gexp2(float y) {
   e = fmaf(t2, e, 1.0f);
   float o = fmaf(t2, 0.00187757667519147912699f, 0.0558263180532956664775f);
   o = fmaf(t2, o, 0.693153073200168932794f);
-  return ldexpf(1.0f, (int)ip) * fmaf(o, fp, e);
+  /* 2^ip is built in the exponent field, (ip + 127) << 23: ip = -127 gives 0.0 (not the denormal 2^-127), ip = 128 +inf */
+  return u2f((uint32_t)((int)ip + 127) << 23) * fmaf(o, fp, e);
 }
 /* svotrace.comp:26-29 */
 static float rand_from_dot(float d) {

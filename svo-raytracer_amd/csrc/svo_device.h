@@ -90,12 +90,13 @@ __device__ __forceinline__ float sincos_pinned(float x) {
 __device__ __forceinline__ float acos_pinned(float x) {
   const float ax = __builtin_fabsf(x);
   float t = ax * (-0.02363318f) + 0.08132463f;
-  t = ax * t + (-0.2145988f);
+  t = ax * t + (0.785398163f - 1.0f);   // (float)(pi/4) - 1 = -0.21460181 (mistyped as -0.2145988 in round 1; tools/probes/fn_probe.comp)
   t = ax * t + 1.5707964f;
   return 1.5707964f - sign_g(x) * (1.5707964f - __builtin_sqrtf(1.0f - ax) * t);
 }
 __device__ __forceinline__ float exp2_pinned(float y) {
-  y = fmin_g(y, 129.0f);
+  if (y != y) return y;   // NaN in, NaN out
+  y = fmin_g(y, 128.0f);
   y = fmax_g(y, -126.99999f);
   const float ip = __builtin_floorf(y);
   const float fp = y - ip;
@@ -104,7 +105,8 @@ __device__ __forceinline__ float exp2_pinned(float y) {
   e = __builtin_fmaf(t2, e, 1.0f);
   float o = __builtin_fmaf(t2, 0.00187757667519147912699f, 0.0558263180532956664775f);
   o = __builtin_fmaf(t2, o, 0.693153073200168932794f);
-  return __builtin_ldexpf(1.0f, (int)ip) * __builtin_fmaf(o, fp, e);
+  // 2^ip is built in the exponent field: ip = -127 gives 0.0 (not the denormal 2^-127), ip = 128 +inf
+  return __uint_as_float((uint32_t)((int)ip + 127) << 23) * __builtin_fmaf(o, fp, e);
 }
 // svotrace.comp:26-29 on the already-formed dot product
 __device__ __forceinline__ float rand_of_dot(float d) {

@@ -15,6 +15,8 @@
 
 Runs only in the build container.  Output: tests/golden/fuzz_golden.npz (data only).
 
+  * hostile cameras and the smallest legal pools (hs_*).
+
     python tests/golden/make_golden_fuzz.py
 """
 import os
@@ -36,7 +38,11 @@ SHADER = "/root/reference/src/shaders/svotrace.comp"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
 OUT = os.path.dirname(os.path.abspath(__file__))
 PAD = 1 << 20
-W, H = 56, 36
+
+
+def size_of(name):
+    return (40, 24) if name.startswith("hs_") else (56, 36)
+
 
 
 def interior_offsets(p, limit=4000):
@@ -102,7 +108,40 @@ def cases():
     pools["s128"] = scene.build_scene(128)[0]
     for fr in (-5, 1000000, 16777216, 123456789, 300000000, 2147483647, -2147483648):
         cs.append(("s128_K1_m0_f%d" % fr, "s128", cams["K1"].copy(), fr, 0))
+    # hostile cameras on the terrain scene (NaN / infinite / huge / denormal components, zero-length and identical corner
+    # rays, the camera on faces, corners and cell boundaries of the cube, far outside, inside solid voxels) and the
+    # smallest legal pools; smaller images (HW, HH) -- most of these frames are flat
+    for k, cam in enumerate(hostile_cameras(np.array(CAMERAS["K1"], dtype=np.float32))):
+        for mode in (0, 1, 2, 3):
+            cs.append(("hs_s128_c%d_m%d" % (k, mode), "s128", cam, 2 + k, mode))
+    surf = [1, 0, 0, 0, 7, 0x55, 0x55]
+    for i in range(8):
+        surf += [1 + i % 3, (455 + 20 * i) & 0xff, (455 + 20 * i) >> 8]
+    tiny = {"t_root": [1, 0, 0, 0, 0, 0, 0], "t_loop": [1, 0, 0, 0, 0, 0, 0, 0],
+            "t_leaves": [1, 0, 0, 0, 7, 0xff, 0xff] + [1, 0, 2, 0, 3, 0, 0, 5], "t_surf": surf}
+    for pk, b in tiny.items():
+        pools[pk] = np.array(b, dtype=np.uint8)
+        for cn in ("K0", "K1", "K2"):
+            for mode in (0, 1, 2, 3):
+                cs.append(("hs_%s_%s_m%d" % (pk, cn, mode), pk, np.array(CAMERAS[cn], dtype=np.float32), 2, mode))
     return pools, cs
+
+
+def hostile_cameras(base):
+    cams = []
+    for idx, val in ((0, np.nan), (1, np.inf), (2, -np.inf), (4, np.nan), (7, np.inf), (9, 0.0), (13, -0.0), (5, 1e30), (3, 1e-30),
+                     (0, 1e30), (1, -1e30), (6, 1e-45), (10, 3e38)):
+        c = base.copy()
+        c[idx] = val
+        cams.append(c)
+    z = base.copy(); z[3:] = 0.0; cams.append(z)                                       # normalize(0) = NaN
+    n = base.copy(); n[:] = np.nan; cams.append(n)
+    for d in ((0.0, -1.0, 0.0), (1.0, 0.0, 0.0), (-1.0, -1.0, -1.0)):                  # one direction for every pixel
+        a = base.copy(); a[3:6] = a[6:9] = a[9:12] = a[12:15] = d; cams.append(a)
+    for pos in ((1.0, 1.5, 1.5), (2.0, 2.0, 2.0), (1.5, 1.5, 1.5), (1.25, 1.5, 1.75), (40.0, 30.0, -25.0), (-1e6, 1.5, 1.5),
+                (1.5, 1.01, 1.5)):
+        f = base.copy(); f[:3] = pos; cams.append(f)
+    return cams
 
 
 BIG_FRAMES = (0, -7, 1000000, 8000000, 16777216, 60000000, 100000000, 215000000, 216000000, 1000000000, 2147483647, -2147483648)
@@ -131,12 +170,47 @@ def sin_probe(tmp, out):
     out["sinprobe/index"] = np.array(["%d_%d" % (fr, m) for fr in BIG_FRAMES for m in (0, 1, 2)])
 
 
+def _bits(v):
+    return struct.unpack("<I", struct.pack("<f", v))[0]
+
+
+FN_BASES = {   # renderMode of tools/probes/fn_probe.comp -> bit patterns the 2 048 consecutive arguments start from
+    0: [_bits(1.0) - 1000, _bits(-1.0) - 1000, _bits(0.0), 0x7f800000 - 1000, 0xff800000 - 1000, _bits(0.99), _bits(0.5) - 1000,
+        _bits(-0.3), 0x80000000, _bits(2.0), _bits(0.92) - 1000],
+    1: [_bits(0.0), _bits(1.0), _bits(87.0), _bits(126.0) - 500, _bits(87.33) - 1000, _bits(88.0), _bits(130.0), 0x7f800000 - 1000,
+        _bits(-1.0), _bits(-87.0), _bits(-88.5) - 1000, _bits(-88.72) - 1000, _bits(-126.0) - 500, _bits(-200.0), 1, 0x80000000,
+        0xff800000 - 1000, _bits(-89.0), _bits(0.3), _bits(3.0)],
+}
+FW, FH = 64, 32
+
+
+def fn_probe(tmp, out):
+    """llvmpipe's acos() and the fog term exp(-0.5 * x * 2) at chosen bit patterns (tools/probes/fn_probe.comp)"""
+    job = ["size %d %d" % (FW, FH)]
+    for m, bl in FN_BASES.items():
+        for b in bl:
+            job += ["frame %d" % (b if b < 0x80000000 else b - (1 << 32)), "mode %d" % m, "ptrpatch 0",
+                    "render " + os.path.join(tmp, "fp%d_%08x" % (m, b))]
+    r = subprocess.run([REF_BIN, os.path.join(ROOT, "tools", "probes", "fn_probe.comp"), "raw"],
+                       input=("\n".join(job) + "\n").encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    keys = []
+    for m, bl in FN_BASES.items():
+        for b in bl:
+            k = "%d_%08x" % (m, b)
+            out["fnprobe/%s/x_bits" % k] = (np.uint32(b) + np.arange(FW * FH, dtype=np.uint32)).astype(np.uint32)
+            out["fnprobe/%s/ref_bits" % k] = np.fromfile(os.path.join(tmp, "fp" + k + ".depth"), dtype=np.uint32)
+            keys.append(k)
+    out["fnprobe/index"] = np.array(keys)
+
+
 def main():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     pools, cs = cases()
     tmp = tempfile.mkdtemp(prefix="golden_fuzz_")
-    job, cur = ["pad %d" % PAD, "size %d %d" % (W, H)], None
+    job, cur = ["pad %d" % PAD], None
     for name, pk, cam, frame, mode in cs:
+        job.append("size %d %d" % size_of(name))
         if pk != cur:
             path = os.path.join(tmp, pk + ".bin")
             pools[pk].tofile(path)
@@ -150,6 +224,7 @@ def main():
     assert r.returncode == 0
     out, index = {}, []
     for name, pk, cam, frame, mode in cs:
+        W, H = size_of(name)
         rgba = np.fromfile(os.path.join(tmp, name + ".rgba"), dtype=np.uint8).reshape(H, W, 4)
         depth = np.fromfile(os.path.join(tmp, name + ".depth"), dtype=np.uint32).reshape(H, W)
         rgba_p = np.fromfile(os.path.join(tmp, name + "_p.rgba"), dtype=np.uint8).reshape(H, W, 4)
@@ -168,6 +243,7 @@ def main():
         out["pool/" + pk] = p
     out["index"] = np.array(index)
     sin_probe(tmp, out)
+    fn_probe(tmp, out)
     path = os.path.join(OUT, "fuzz_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(cs), "cases")

@@ -34,8 +34,8 @@ def _golden(name):
 
 def test_fixture_is_what_the_generator_describes():
     cases = _cases()
-    assert len(cases) >= 180
-    assert {pk[0] for _, pk in cases} == {"f", "m", "s"}
+    assert len(cases) >= 300
+    assert {pk[0] for _, pk in cases} == {"f", "m", "s", "t"}
     assert {int(_z()[n + "/meta"][2]) for n, _ in cases} >= {2147483647, -2147483648, 16777216}
     assert {int(_z()[n + "/meta"][3]) for n, _ in cases} >= {0, 1, 2, 3, 4, 5, -1}
 
@@ -87,3 +87,26 @@ def test_oracle_sin_cos_at_large_arguments_are_llvmpipe_s():
         assert np.array_equal(mine, ref), key
         n += int((np.abs(ref.view(np.float32)) == 1.0).sum())
     assert n > 1000   # the clamp is really exercised
+
+
+def test_oracle_acos_and_fog_exp_are_llvmpipe_s():
+    """acos() around +-1, 0, 0.5, beyond 1, NaN / inf; the fog term exp(-0.5 x 2) = exp2(x * -log2(e)) across its clamps
+    (the smallest results are built in the exponent field: 0.0, not a denormal), NaN in -> NaN out.  45 000 arguments."""
+    import ctypes
+    from oracle import oracle
+    L = oracle.lib()
+    for fn in (L.svo_oracle_acos, L.svo_oracle_exp2):
+        fn.restype = ctypes.c_float
+        fn.argtypes = [ctypes.c_float]
+    z = _z()
+    with np.errstate(all="ignore"):
+        for key in z["fnprobe/index"]:
+            x = z["fnprobe/%s/x_bits" % key].view(np.float32)
+            ref = z["fnprobe/%s/ref_bits" % key]
+            if key.startswith("0_"):
+                mine = np.array([L.svo_oracle_acos(float(v)) for v in x], dtype=np.float32)
+            else:
+                k = np.float32(-0.5 * 2 * 1.44269504)
+                mine = np.array([L.svo_oracle_exp2(float(np.float32(v) * k)) for v in x], dtype=np.float32)
+            both_nan = np.isnan(mine) & np.isnan(ref.view(np.float32))
+            assert not ((mine.view(np.uint32) != ref) & ~both_nan).any(), key
