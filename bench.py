@@ -22,8 +22,8 @@ depth in one message) are gathered to rank 0 over xGMI (one direct send per peer
 the next frames' traversal.  --scaling weak keeps 1920x1080 pixels per GPU instead (the frame grows
 to 1920 x 1080*N rows of the same view).
 
-Throughput configuration (all of it on the JSON line): --inflight 3 dispatches in flight on alternating streams, each
-dispatch a batch of --batch 4 consecutive frames (svo_set_batch: one persistent launch whose waves run from frame to
+Throughput configuration (all of it on the JSON line): --inflight 4 dispatches in flight on alternating streams, each
+dispatch a batch of --batch 5 consecutive frames (svo_set_batch: one persistent launch whose waves run from frame to
 frame, so the launch's tail is paid once per batch).  A step is still ONE frame: K steps = K frames, the last dispatch
 a partial batch if need be.  `--inflight 1 --batch 1` is the reference's own loop, one frame at a time.
 
@@ -52,8 +52,12 @@ VALU_CYCLES = 2.5       # measured: a SIMD retires one wave64 VALU instruction p
 
 # frames per dispatch when --batch is not given (the same for every number of GPUs, so that the scaling curve compares like
 # with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N
-# (tools/r02_batch_probe.sh, tools/r02_batch.sh: 1 GPU 4.38 -> 4.54 Grays/s; rank 0 of 8: 0.152 -> 0.106 ms per frame)
-DEFAULT_BATCH = {1: 4, 2: 4, 4: 4, 8: 4}
+# (tools/r02_batch_probe.sh, tools/r02_batch.sh: 1 GPU 4.38 -> 4.54 Grays/s; rank 0 of 8: 0.152 -> 0.106 ms per frame).
+# 4 dispatches in flight x 5 frames instead of 3 x 4 (tools/r03_shortrun*.sh): the same in a long run (4.58 against 4.53
+# Grays/s at 400 steps) and much less lost to the start and the drain of a short timed region -- 20 steps: 4.43 against
+# 4.13, 40 steps: 4.50 against 4.14 (20 steps = four dispatches that start together and end together)
+DEFAULT_BATCH = {1: 5, 2: 5, 4: 5, 8: 5}
+DEFAULT_INFLIGHT = 4
 
 PRESETS = {
     # name: size, width, height, mode, bounces (path segments), mirror mask, spp
@@ -81,7 +85,7 @@ def parse(argv=None):
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SVO_BENCH_PIPELINE", "1")),
                     help="0 one thread per pixel, 1 persistent waves (default), 2 staged wavefront")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SVO_BENCH_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SVO_BENCH_INFLIGHT", str(DEFAULT_INFLIGHT))),
                     help="frames in flight (streams x output buffers); the next frame fills the GPU while the "
                          "previous one drains its longest paths")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SVO_BENCH_BATCH", "0")),
@@ -167,7 +171,7 @@ def default_batch(args, world):
     (the library folds them into it), so such frames go one per dispatch."""
     if args.spp > 1:
         return 1
-    return DEFAULT_BATCH.get(world, 4 if world > 8 else 1)
+    return DEFAULT_BATCH.get(world, 5 if world > 8 else 1)
 
 
 def pmc_key(args, width, height, nbuf, batch):

@@ -92,31 +92,33 @@ def test_bench_configuration_frames_in_flight_8192_1080p(ctx, pool8192):
         # consecutive frames really are different frames (bounce directions change with frameNumber)
         assert not np.array_equal(fr.get(0)["rgba"], fr.get(1)["rgba"])
         alone = [fr.get(k) for k in range(9)]
-        # bench.py's default: 3 dispatches in flight, each ONE launch of 4 consecutive frames (svo_set_batch)
+        # bench.py's default: 4 dispatches in flight, each ONE launch of 5 consecutive frames (svo_set_batch)
         import torch
-        nb = 4
-        col = [torch.zeros((nb, h, w), dtype=torch.int32, device="cuda") for _ in range(3)]
-        dep = [torch.zeros((nb, h, w), dtype=torch.float32, device="cuda") for _ in range(3)]
-        hit = [torch.zeros((nb, h, w, 4), dtype=torch.int32, device="cuda") for _ in range(3)]
+        from svo_raytracer_amd import hiplib
+        nd, nb = 4, 5
+        col = [torch.zeros((nb, h, w), dtype=torch.int32, device="cuda") for _ in range(nd)]
+        dep = [torch.zeros((nb, h, w), dtype=torch.float32, device="cuda") for _ in range(nd)]
+        hit = [torch.zeros((nb, h, w, 4), dtype=torch.int32, device="cuda") for _ in range(nd)]
+        streams = [torch.cuda.Stream() for _ in range(nd)]
         torch.cuda.synchronize()
         ctx.set_tuning(10, 9)
         ctx.set_batch(nb, w * h)
-        for b in range(3):
-            ctx.set_stream(fr.streams[b].cuda_stream)
+        for b in range(nd):
+            ctx.set_stream(streams[b].cuda_stream)
             ctx.bind_outputs(col[b].data_ptr(), dep[b].data_ptr(), hit[b].data_ptr())
             ctx.set_params(2 + b * nb, 0, 0, 0, 2, 0, 1)
             ctx.dispatch_async()
         torch.cuda.synchronize()
         ctx.set_batch(1, 0)
-        for b in range(3):
+        fr.done()                      # back to the library's own images, one frame at a time
+        ctx.set_tuning(0, 0)
+        for b in range(nd):
             for k in range(nb):
                 f = b * nb + k
-                if f >= 9:
-                    break
-                from svo_raytracer_amd import hiplib
                 got = {"rgba": col[b][k].cpu().numpy().view(np.uint8).reshape(h, w, 4), "depth": dep[b][k].cpu().numpy(),
                        "hits": hit[b][k].cpu().numpy().reshape(-1, 4).copy().view(hiplib.HIT_DTYPE).reshape(h, w)}
-                assert _eq(got, alone[f]), "frame %d of a batched launch differs from the frame rendered alone" % (2 + f)
+                want = alone[f] if f < 9 else ctx.render(None, None, None, None, 2 + f, 0)
+                assert _eq(got, want), "frame %d of a batched launch differs from the frame rendered alone" % (2 + f)
     finally:
         ctx.set_batch(1, 0)
         fr.done()

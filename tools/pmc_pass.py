@@ -2,7 +2,7 @@
 """Collect the per-launch PMC figures bench.py reports next to its roofline (GPU box only).
 
 Runs the bench command under rocprofv3 in SEPARATE short passes (the guide: FETCH_SIZE and WRITE_SIZE do not fit
-one pass; PMC runs carry no trace flags), averages each counter over the dispatches of the dominant kernel, and
+one pass; PMC runs carry no trace flags; whole batches only, so that every launch counted carries the same number of frames), averages each counter over the dispatches of the dominant kernel, and
 writes gpurun_out/pmc_per_launch.json keyed like bench.py keys it, stamped with the hash of the kernel sources:
 bench.py only reports figures whose hash matches the sources it runs (copy the file to profiles/ to commit it).
 
@@ -51,7 +51,7 @@ def main():
         subprocess.call(["rm", "-rf", d])
         cmd = ["timeout", "-s", "KILL", "300", "rocprofv3", "--pmc"] + counters + \
               ["--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-               "--steps", "32", "--warmup", "4", "--cpu-seconds", "0", "--verify", "0", "--isolated", "0"] + bench_args
+               "--steps", str(8 * batch), "--warmup", str(batch), "--cpu-seconds", "0", "--verify", "0", "--isolated", "0"] + bench_args
         with open(os.path.join(out_root, name + ".log"), "w") as lf:
             rc = subprocess.call(cmd, cwd="/tmp", env=env, stdout=lf, stderr=subprocess.STDOUT)
         print("pass %s rc %d" % (name, rc), flush=True)
@@ -75,7 +75,7 @@ def main():
         "sq_insts_valu": means["SQ_INSTS_VALU"], "sq_active_inst_valu": means["SQ_ACTIVE_INST_VALU"],
         "sq_thread_cycles_valu": means["SQ_THREAD_CYCLES_VALU"],
         "other": {k: v for k, v in means.items() if k not in need},
-        "how": "rocprofv3 --pmc, separate passes of `bench.py --steps 32 --warmup 4 --verify 0 --isolated 0 " + " ".join(bench_args) +
+        "how": "rocprofv3 --pmc, separate passes of `bench.py --steps %d --warmup %d --verify 0 --isolated 0 " % (8 * batch, batch) + " ".join(bench_args) +
                "`, per-dispatch mean over the kernel's launches; traffic = FETCH_SIZE x 2 (gfx950: 128-B requests "
                "tallied at 64 B, profiles/r01_fetch_size_calibration.txt) + WRITE_SIZE, both in KB",
     }
