@@ -121,7 +121,8 @@ def _worker(rank, world, port, w, h, nbuf, steps, want_hits, out_path, batch=1):
 
 
 @pytest.mark.parametrize("world,h,nbuf,steps,want_hits,batch", [(2, 96, 3, 5, False, 1), (2, 100, 2, 3, True, 1),
-                                                                   (3, 116, 3, 4, False, 1), (2, 100, 2, 7, True, 3)])
+                                                                   (3, 116, 3, 4, False, 1), (2, 100, 2, 7, True, 3),
+                                                                   (8, 136, 4, 12, False, 5)])   # bench.py's defaults at N = 8
 def test_frame_ring_over_gloo_reassembles_every_frame_in_the_ring(tmp_path, world, h, nbuf, steps, want_hits, batch):
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd.cameras import CAMERAS
