@@ -29,6 +29,9 @@
  *                               (svotrace.comp:712-719, commented out) is switched on in memory
  *   keep <0|1>                  1: the images persist from render to render, as in Main.java
  *   fresh                       drop the persistent images (the next render starts from cleared ones)
+ *   bounces <n>                 path segments of renderMode 0: the literal loop bound 2 of svotrace.comp:444 becomes n
+ *   mirror <0|1>                1: the commented-out material test of svotrace.comp:500-504 is switched on in memory
+ *                               (value 1 scatters, every other value reflects) and the unconditional scatter of :506 off
  *   render <prefix>             writes <prefix>.rgba  <prefix>.depth  [<prefix>.ptr]
  *
  * Build: see oracle/Makefile (output goes to oracle/_ref/, git-ignored).
@@ -233,6 +236,68 @@ static char *apply_accum_patch(const char *src, int first_line, int last_line) {
   return out;
 }
 
+/*
+ * Two more in-memory switches for code the reference carries but does not run (no shader text lives here either):
+ *   bounces N : the literal bound of the path loop of renderMode 0 (`i < 2`, svotrace.comp:444) becomes N;
+ *   mirror    : the commented-out material test of svotrace.comp:500-504 (value 1 scatters, every other value reflects:
+ *               dir - 2 dot(dir, normal) normal) is uncommented and the unconditional scatter of :506 commented out.
+ * Line counts do not change, so the line-addressed patches compose.
+ */
+static char *toggle_lines(const char *src, int first_line, int last_line, int uncomment, const char *must_contain) {
+  char *out = malloc(strlen(src) + 4 * (size_t)(last_line - first_line + 2) + 1), *o = out;
+  int line = 1, checked = 0;
+  const char *p = src;
+  while (*p) {
+    const char *e = strchr(p, '\n');
+    size_t n = e ? (size_t)(e - p) + 1 : strlen(p);
+    if (line >= first_line && line <= last_line) {
+      if (line == first_line) {
+        char tmp[512];
+        size_t m = n < 511 ? n : 511;
+        memcpy(tmp, p, m); tmp[m] = 0;
+        checked = strstr(tmp, must_contain) != NULL;
+      }
+      const char *c = p;
+      while (c < p + n && (*c == ' ' || *c == '\t')) c++;
+      if (uncomment) {
+        if (!(c + 2 <= p + n && c[0] == '/' && c[1] == '/')) { fprintf(stderr, "line %d is not a comment\n", line); exit(2); }
+        memcpy(o, p, (size_t)(c - p)); o += c - p;
+        c += 2;
+        memcpy(o, c, (size_t)(p + n - c)); o += p + n - c;
+      } else {
+        memcpy(o, "//", 2); o += 2;
+        memcpy(o, p, n); o += n;
+      }
+      p += n; line++;
+      continue;
+    }
+    memcpy(o, p, n); o += n;
+    p += n; line++;
+  }
+  *o = 0;
+  if (!checked) { fprintf(stderr, "line %d does not contain \"%s\"\n", first_line, must_contain); exit(2); }
+  return out;
+}
+
+static char *apply_variant(const char *src, int bounces, int mirror) {
+  char *s = strdup(src);
+  if (bounces != 2) {
+    char with[64];
+    int n;
+    snprintf(with, sizeof with, "for(int i=0; i < %d; i++){", bounces);
+    char *t = replace_all(s, "for(int i=0; i < 2; i++){", with, &n);
+    if (n != 1) { fprintf(stderr, "bounce loop anchor: %d\n", n); exit(2); }
+    free(s); s = t;
+  }
+  if (mirror) {
+    char *t = toggle_lines(s, 500, 504, 1, "res.value == 1");
+    free(s);
+    s = toggle_lines(t, 506, 506, 0, "newdir = normalize");
+    free(t);
+  }
+  return s;
+}
+
 static GLuint build_program(const char *src) {
   GLuint sh = glCreateShader(GL_COMPUTE_SHADER);
   glShaderSource(sh, 1, &src, NULL);
@@ -310,6 +375,7 @@ int main(int argc, char **argv) {
   float cam[15] = {1.5f, 1.5f, 2.0f, -1.6f, -0.9f, -1, -1.6f, 0.9f, -1, 1.6f, -0.9f, -1, 1.6f, 0.9f, -1};
   GLuint ssbo = 0;
   size_t pool_len = 0, pad_bytes = 0;
+  int var_bounces = 2, var_mirror = 0;
   char line[8192];
   glPixelStorei(GL_PACK_ALIGNMENT, 1);
   while (fgets(line, sizeof line, stdin)) {
@@ -334,6 +400,16 @@ int main(int argc, char **argv) {
       unsigned long v = 0;
       sscanf(line, "%*s %lu", &v);
       pad_bytes = (size_t)v;
+    } else if (!strcmp(cmd, "bounces") || !strcmp(cmd, "mirror")) {   /* rebuild the programs from the switched source */
+      int v = 0;
+      sscanf(line, "%*s %d", &v);
+      if (!strcmp(cmd, "bounces")) var_bounces = v; else var_mirror = v;
+      if (raw) { fprintf(stderr, "variants need the reference shader\n"); return 2; }
+      char *vs = apply_variant(src, var_bounces, var_mirror);
+      prog_plain = build_program(vs);
+      prog_patched = build_program(apply_ptr_patch(vs));
+      prog_accum = build_program(apply_accum_patch(vs, 712, 719));
+      free(vs);
     } else if (!strcmp(cmd, "size")) {
       sscanf(line, "%*s %d %d", &W, &H);
     } else if (!strcmp(cmd, "cam")) {

@@ -124,6 +124,16 @@ def cases():
         for cn in ("K0", "K1", "K2"):
             for mode in (0, 1, 2, 3):
                 cs.append(("hs_%s_%s_m%d" % (pk, cn, mode), pk, np.array(CAMERAS[cn], dtype=np.float32), 2, mode))
+    # path options the shader carries but does not run, switched on in memory by the harness (`bounces n`: the literal
+    # bound of the path loop, svotrace.comp:444; `mirror 1`: the commented-out material test of :500-504 -- value 1
+    # scatters, every other value reflects = mirror_mask 0xfffffffd here)
+    pools["f1d6"] = fuzzpool.random_pool(1, max_depth=6, p_interior=0.8, p_empty=0.8)
+    for pk in ("s128", "f1d6"):
+        for bounces, mirror in ((1, 0), (3, 0), (5, 0), (2, 1), (4, 1)):
+            for cn in ("K1", "K0"):
+                for fr in (2, 9):
+                    cs.append(("pv_%s_b%d_r%d_%s_f%d" % (pk, bounces, mirror, cn, fr), pk, cams[cn].copy(), fr, 0,
+                               dict(bounces=bounces, mirror=mirror)))
     return pools, cs
 
 
@@ -209,7 +219,12 @@ def main():
     pools, cs = cases()
     tmp = tempfile.mkdtemp(prefix="golden_fuzz_")
     job, cur = ["pad %d" % PAD], None
-    for name, pk, cam, frame, mode in cs:
+    variant = (2, 0)
+    for name, pk, cam, frame, mode, *opt in cs:
+        want = (opt[0]["bounces"], opt[0]["mirror"]) if opt else (2, 0)
+        if want != variant:
+            job += ["bounces %d" % want[0], "mirror %d" % want[1]]
+            variant = want
         job.append("size %d %d" % size_of(name))
         if pk != cur:
             path = os.path.join(tmp, pk + ".bin")
@@ -223,7 +238,7 @@ def main():
     sys.stderr.write(r.stderr.decode()[-600:])
     assert r.returncode == 0
     out, index = {}, []
-    for name, pk, cam, frame, mode in cs:
+    for name, pk, cam, frame, mode, *opt in cs:
         W, H = size_of(name)
         rgba = np.fromfile(os.path.join(tmp, name + ".rgba"), dtype=np.uint8).reshape(H, W, 4)
         depth = np.fromfile(os.path.join(tmp, name + ".depth"), dtype=np.uint32).reshape(H, W)
@@ -238,6 +253,8 @@ def main():
         out[name + "/first_hit"] = ptr
         out[name + "/cam"] = np.asarray(cam, dtype=np.float32)
         out[name + "/meta"] = np.array([W, H, frame, mode, int(same)], dtype=np.int32)
+        if opt:   # path options: segments, mirror mask
+            out[name + "/path"] = np.array([opt[0]["bounces"], 0xfffffffd if opt[0]["mirror"] else 0], dtype=np.uint32)
         index.append(name + ":" + pk)
     for pk, p in pools.items():
         out["pool/" + pk] = p

@@ -1,7 +1,8 @@
 """Pools no builder produces, under the reference shader itself (tests/golden/fuzz_golden.npz, made by
 tests/golden/make_golden_fuzz.py on Mesa llvmpipe): random tag / value / normal mixes, child pointers that point
 backwards, into the middle of other records and into the zero bytes behind the tree; every render mode, incl. the
-ones trace() has no branch for.  The oracle and the three HIP pipelines against those vectors, bit for bit."""
+ones trace() has no branch for; hostile cameras; frame numbers up to +-2^31; and the path options the shader carries
+but does not run (more or fewer path segments, the mirror material), switched on in memory by the harness.  The oracle and the three HIP pipelines against those vectors, bit for bit."""
 import os
 
 import numpy as np
@@ -28,14 +29,16 @@ def _cases():
 def _golden(name):
     z = _z()
     w, h, frame, mode, same = (int(v) for v in z[name + "/meta"])
+    path = z[name + "/path"] if name + "/path" in z.files else (2, 0)
     return dict(w=w, h=h, frame=frame, mode=mode, patched_same=bool(same), cam=z[name + "/cam"], rgba=z[name + "/rgba"],
-                depth_bits=z[name + "/depth_bits"], first_hit=z[name + "/first_hit"])
+                depth_bits=z[name + "/depth_bits"], first_hit=z[name + "/first_hit"], bounces=int(path[0]), mirror_mask=int(path[1]))
 
 
 def test_fixture_is_what_the_generator_describes():
     cases = _cases()
-    assert len(cases) >= 300
-    assert {pk[0] for _, pk in cases} == {"f", "m", "s", "t"}
+    assert len(cases) >= 360
+    assert sum(1 for n, _ in cases if n.startswith("pv_")) == 40
+    assert {pk[0] for _, pk in cases} == {"f", "m", "s", "t"}   # fuzz, mangled, scene, tiny
     assert {int(_z()[n + "/meta"][2]) for n, _ in cases} >= {2147483647, -2147483648, 16777216}
     assert {int(_z()[n + "/meta"][3]) for n, _ in cases} >= {0, 1, 2, 3, 4, 5, -1}
 
@@ -45,7 +48,8 @@ def test_oracle_matches_reference_shader_on_fuzz_pools(name, poolkey):
     from oracle import oracle
     g = _golden(name)
     assert g["patched_same"]
-    res = oracle.render(_z()["pool/" + poolkey], g["w"], g["h"], g["cam"], g["frame"], g["mode"])
+    res = oracle.render(_z()["pool/" + poolkey], g["w"], g["h"], g["cam"], g["frame"], g["mode"], bounces=g["bounces"],
+                        mirror_mask=g["mirror_mask"])
     bad = compare_with_golden(res, g)
     assert bad == {k: 0 for k in bad}, bad
 
@@ -62,7 +66,8 @@ def test_hip_matches_reference_shader_on_fuzz_pools(poolkey):
             ctx.set_pipeline(pipeline)
             for i, name in enumerate(names):
                 g = _golden(name)
-                res = ctx.render(pool if i == 0 else None, g["w"], g["h"], g["cam"], g["frame"], g["mode"])
+                res = ctx.render(pool if i == 0 else None, g["w"], g["h"], g["cam"], g["frame"], g["mode"],
+                                 bounces=g["bounces"], mirror_mask=g["mirror_mask"])
                 bad = compare_with_golden(res, g)
                 assert bad == {k: 0 for k in bad}, (name, pipeline, bad)
     finally:
