@@ -9,7 +9,7 @@ ctx = hiplib.HipContext(0)
 ctx.pool_upload(pool); ctx.resize(1920, 1080); ctx.set_camera(CAMERAS["K1"]); ctx.set_hit_records(False); ctx.set_pipeline(1)
 L = hiplib.lib()
 L.svo_debug_heads.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-for wpc in (4, 8, 12, 16, 20):
+for wpc in (10, 20):
     t = 9
     ctx.set_tuning(wpc, t)
     ctx.set_params(2, 0, 0, 0, 2, 0, 1)
