@@ -52,8 +52,8 @@ VALU_CYCLES = 2.5       # measured: a SIMD retires one wave64 VALU instruction p
 
 # frames per dispatch when --batch is not given (the same for every number of GPUs, so that the scaling curve compares like
 # with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N
-# (tools/r02_batch_probe.sh, tools/r02_batch.sh: 1 GPU 4.38 -> 4.54 Grays/s; rank 0 of 8: 0.152 -> 0.106 ms per frame).
-# 4 dispatches in flight x 5 frames instead of 3 x 4 (tools/r03_shortrun*.sh): the same in a long run (4.58 against 4.53
+# (tools/history/r02_batch_probe.sh, tools/history/r02_batch.sh: 1 GPU 4.38 -> 4.54 Grays/s; rank 0 of 8: 0.152 -> 0.106 ms per frame).
+# 4 dispatches in flight x 5 frames instead of 3 x 4 (tools/history/r03_shortrun*.sh): the same in a long run (4.58 against 4.53
 # Grays/s at 400 steps) and much less lost to the start and the drain of a short timed region -- 20 steps: 4.43 against
 # 4.13, 40 steps: 4.50 against 4.14 (20 steps = four dispatches that start together and end together)
 DEFAULT_BATCH = {1: 5, 2: 5, 4: 5, 8: 5}
@@ -266,7 +266,7 @@ def main():
     waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
     if args.pipeline == 1:
         ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and
-                                            # frame, rounds once 7/16 of the traversing lanes have stopped (tools/sweep*.sh)
+                                            # frame, rounds once 7/16 of the traversing lanes have stopped (tools/history/sweep*.sh)
     ctx.set_hit_records(bool(args.hits))
     params = dict(render_mode=args.mode, buffer_end=nbytes, use_beam=args.beam, bounces=args.bounces,
                   mirror_mask=args.mirror, spp=args.spp)

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #endif
     // ---------------- refill idle lanes: ballot + prefix count, one atomic per wave
     // (a wave whose band is used up tries the next band in its next round; SVO_STEAL_NOW=1 tries it in the same round:
-    // 1-4 % slower -- tools/r03_ab_drain.sh)
+    // 1-4 % slower -- tools/history/r03_ab_drain.sh)
     while (bands_left > 0) {
       const unsigned long long idle = __ballot(status == ST_IDLE);
       if (idle == 0ull) break;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 }
 
 // a.fold > 1: tiles per group of a band's walk.  1 / 8 / 64 / 512 / all: 4.47 / 4.49 / 4.47 / 4.41 / 4.20 Grays/s at 64
-// samples per pixel (tools/r03_fold2.sh): a group's samples should be in flight together, not a whole band's
+// samples per pixel (tools/history/r03_fold2.sh): a group's samples should be in flight together, not a whole band's
 constexpr int kFoldGroup = 8;
 constexpr int kHeadSets = 8;   // counter sets: one per frame in flight (its sample launches follow one another on one
                                // stream and share it), reused round-robin
@@ -411,7 +411,7 @@ struct PersistBuffers {
   bool facc_used[kFaccSets] = {};
   size_t facc_floats = 0;   // floats in each colour-sum buffer
   int blocks = 0;
-  int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/sweep8.sh)
+  int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/history/sweep8.sh)
   int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
   int max_per_cu = 16, cus = 256;
   unsigned launches = 0, frames = 0;

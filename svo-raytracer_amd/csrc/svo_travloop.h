@@ -44,7 +44,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The second dword of a child record (low byte of the child pointer, tag mask) only matters to a lane that can
 // still descend into the child.  SVO_LOAD2_NARROWED=1 asks for it on those lanes only (a ray that stops on an
 // interior or tag-2 record then fetches the dword once, after the loop, in trav_result_regs): measured 2.4 % SLOWER
-// than both dwords for every active lane right behind the address (tools/r03_ab_ld2.sh) -- the texture path's cost
+// than both dwords for every active lane right behind the address (tools/history/r03_ab_ld2.sh) -- the texture path's cost
 // is per wave-level load, not per lane, and the narrowed load leaves ~15 instructions later.  Kept as an A/B switch.
 #ifndef SVO_LOAD2_NARROWED
 #define SVO_LOAD2_NARROWED 0

@@ -71,7 +71,7 @@ class FrameRing:
         if self.cuda:
             # one stream of its own per dispatch in flight (not torch's default stream).  HIP maps streams onto a small
             # number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default): two of these streams on one queue serialise
-            # their launches (3.6 instead of 4.5 Grays/s, tools/r02_streams.sh), so the process should raise the limit
+            # their launches (3.6 instead of 4.5 Grays/s, tools/history/r02_streams.sh), so the process should raise the limit
             # before it touches the GPU -- bench.py sets GPU_MAX_HW_QUEUES=8.
             main = torch.cuda.current_stream()
             self.streams = [torch.cuda.Stream() for _ in range(self.nbuf)]

@@ -11,4 +11,4 @@ for fb in 0 4294967296; do
   echo -n "C5 --as-rank 0/8 SVO_FOLD_BYTES=$fb: "
   SVO_FOLD_BYTES=$fb python bench.py --config C5 --as-rank 0/8 --cpu-seconds 0 --steps 12 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['verified'])"
 done
-bash tools/r03_fold_trace.sh
+bash tools/history/r03_fold_trace.sh
