@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 3 -- the benchmark's own configuration: 8192^3 procedural SVO, 1920x1080, primary + 1 bounce,
+camera K1 -- rendered by the reference shader itself under llvmpipe (oracle/_ref/llvmpipe_ref, shader read from
+/root/reference at run time; 1.4 s per frame on the build container's 8 cores = 2.4 Mrays/s).  Also renderMode 2 (the
+reference's default) and the 4K / 5-segment / mirror frame of config 4.  Every STEP-th pixel in x and y of colour, depth
+and the first cast's hit record is kept (the 1.44 GB pool is not stored: the generator is deterministic, a CRC of the
+pool is kept to catch drift).  Runs only in the build container.   python tests/golden/make_golden_config3.py"""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import svo_raytracer_amd.scene as scene  # noqa: E402
+from svo_raytracer_amd.cameras import CAMERAS  # noqa: E402
+
+SHADER = "/root/reference/src/shaders/svotrace.comp"
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
+STEP = 8
+# name, width, height, camera, frameNumber, renderMode, path segments, mirror test (svotrace.comp:500-504 switched on)
+CASES = [("c3_f2", 1920, 1080, "K1", 2, 0, 2, 0), ("c3_f57", 1920, 1080, "K1", 57, 0, 2, 0), ("c3_K0_f3", 1920, 1080, "K0", 3, 0, 2, 0),
+         ("c3_m2", 1920, 1080, "K1", 2, 2, 2, 0), ("c4_f2", 3840, 2160, "K1", 2, 0, 5, 1)]
+
+
+def main():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    pool, _ = scene.build_scene(8192)
+    tmp = tempfile.mkdtemp(prefix="golden_c3_")
+    pool.tofile(os.path.join(tmp, "pool.bin"))
+    out = {"pool_crc32": np.array([zlib.crc32(pool.tobytes())], dtype=np.uint32), "pool_size": np.array([pool.size]),
+           "step": np.array([STEP])}
+    job = ["pool " + os.path.join(tmp, "pool.bin")]
+    variant = (2, 0)
+    for name, w, h, camname, frame, mode, bounces, mirror in CASES:
+        if (bounces, mirror) != variant:
+            job += ["bounces %d" % bounces, "mirror %d" % mirror]
+            variant = (bounces, mirror)
+        hexs = " ".join("%08x" % struct.unpack("<I", struct.pack("<f", float(v)))[0] for v in CAMERAS[camname])
+        job += ["size %d %d" % (w, h), "cam " + hexs, "frame %d" % frame, "mode %d" % mode, "ptrpatch 1",
+                "render " + os.path.join(tmp, name)]
+    r = subprocess.run([REF_BIN, SHADER], input=("\n".join(job) + "\n").encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    for name, w, h, camname, frame, mode, bounces, mirror in CASES:
+        p = os.path.join(tmp, name)
+        sub = (slice(0, h, STEP), slice(0, w, STEP))
+        out[name + "/rgba"] = np.fromfile(p + ".rgba", dtype=np.uint8).reshape(h, w, 4)[sub].copy()
+        out[name + "/depth_bits"] = np.fromfile(p + ".depth", dtype=np.uint32).reshape(h, w)[sub].copy()
+        out[name + "/first_hit"] = np.fromfile(p + ".ptr", dtype=np.uint32).reshape(h, w, 4)[sub].copy()
+        out[name + "/cam"] = np.asarray(CAMERAS[camname], dtype=np.float32)
+        out[name + "/meta"] = np.array([w, h, frame, mode, bounces, mirror], dtype=np.int32)
+        print(name, "hits in the subsample", int((out[name + "/first_hit"][..., 0] != 0).sum()), "of", out[name + "/rgba"].shape[:2])
+    out["index"] = np.array([c[0] for c in CASES])
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config3_8192.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""BASELINE.json config 3 -- what bench.py measures: 8192^3 procedural SVO, 1920x1080, primary + 1 bounce -- and the 4K /
+5-segment / mirror frame of config 4, against the reference shader's own output at full size (llvmpipe golden of every
+8th pixel in x and y: tests/golden/make_golden_config3.py).  CPU leg: the oracle on the same pixels.  GPU leg: the HIP
+pipelines' full frames, sampled; for the persistent pipeline also as bench.py runs it (frames in flight, batched)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import svo_raytracer_amd.scene as scene
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_8192.npz")
+
+
+def _cases():
+    return [str(n) for n in np.load(GOLD)["index"]]
+
+
+@pytest.fixture(scope="module")
+def pool8192():
+    z = np.load(GOLD)
+    pool, _ = scene.build_scene(8192)
+    assert pool.size == int(z["pool_size"][0]) and zlib.crc32(pool.tobytes()) == int(z["pool_crc32"][0]), \
+        "scene generator drifted: regenerate tests/golden/config3_8192.npz"
+    return pool
+
+
+def _meta(z, name):
+    w, h, frame, mode, bounces, mirror = (int(v) for v in z[name + "/meta"])
+    return w, h, frame, mode, bounces, (0xfffffffd if mirror else 0)
+
+
+def _check(res, z, name, step, sampled=False):
+    """res: full-size images (sampled=False) or images that only hold every step-th pixel's value at its place"""
+    sub = (slice(0, res["rgba"].shape[0], step), slice(0, res["rgba"].shape[1], step))
+    fh = z[name + "/first_hit"]
+    hit = fh[..., 0] != 0
+    assert (res["rgba"][sub] == z[name + "/rgba"]).all(), name
+    assert (res["depth"].view(np.uint32)[sub] == z[name + "/depth_bits"]).all(), name
+    h = res["hits"]
+    assert (h["pointer"][sub] == fh[..., 0]).all(), name                 # hit voxel IDs
+    assert ((h["value"][sub] == fh[..., 1]) | ~hit).all(), name
+    assert ((h["raw_normal"][sub] == fh[..., 2]) | ~hit).all(), name     # packed normals
+    assert ((h["level"][sub] == (fh[..., 3] >> 16)) | ~hit).all(), name
+    assert ((h["iter"][sub] == (fh[..., 3] & 0xFFFF)) | ~hit).all(), name
+
+
+@pytest.mark.parametrize("name", _cases())
+def test_config3_oracle_matches_reference_at_full_size(pool8192, name):
+    from oracle import oracle
+    z = np.load(GOLD)
+    step = int(z["step"][0])
+    w, h, frame, mode, bounces, mirror = _meta(z, name)
+    res = oracle.render(pool8192, w, h, z[name + "/cam"], frame, mode, bounces=bounces, mirror_mask=mirror, xstep=step, ystep=step)
+    _check(res, z, name, step)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_config3_hip_matches_reference_at_full_size(pool8192, pipeline):
+    from svo_raytracer_amd import hiplib
+    z = np.load(GOLD)
+    step = int(z["step"][0])
+    ctx = hiplib.HipContext(0)
+    try:
+        ctx.set_pipeline(pipeline)
+        ctx.pool_upload(pool8192)
+        for name in _cases():
+            w, h, frame, mode, bounces, mirror = _meta(z, name)
+            res = ctx.render(None, w, h, z[name + "/cam"], frame, mode, bounces=bounces, mirror_mask=mirror)
+            _check(res, z, name, step)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_config3_as_the_benchmark_runs_it(pool8192):
+    """frames 2 and 57 of the golden inside bench.py's throughput configuration: svo_set_tuning(10, 9), 4 dispatches of 5
+    frames in flight on 4 streams (frames 2..21 and 42..61), the two golden frames picked out of their batches"""
+    import torch
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    z = np.load(GOLD)
+    step = int(z["step"][0])
+    w, h = 1920, 1080
+    ctx = hiplib.HipContext(0)
+    try:
+        ctx.set_pipeline(1)
+        ctx.pool_upload(pool8192)
+        ctx.resize(w, h)
+        ctx.set_camera(CAMERAS["K1"])
+        ctx.set_tuning(10, 9)
+        nd, nb = 4, 5
+        for first, want in ((2, ("c3_f2", 2)), (42, ("c3_f57", 57))):
+            col = [torch.zeros((nb, h, w), dtype=torch.int32, device="cuda") for _ in range(nd)]
+            dep = [torch.zeros((nb, h, w), dtype=torch.float32, device="cuda") for _ in range(nd)]
+            hit = [torch.zeros((nb, h, w, 4), dtype=torch.int32, device="cuda") for _ in range(nd)]
+            streams = [torch.cuda.Stream() for _ in range(nd)]
+            torch.cuda.synchronize()
+            ctx.set_batch(nb, w * h)
+            for b in range(nd):
+                ctx.set_stream(streams[b].cuda_stream)
+                ctx.bind_outputs(col[b].data_ptr(), dep[b].data_ptr(), hit[b].data_ptr())
+                ctx.set_params(first + b * nb, 0, 0, 0, 2, 0, 1)
+                ctx.dispatch_async()
+            torch.cuda.synchronize()
+            b, k = divmod(want[1] - first, nb)
+            res = {"rgba": col[b][k].cpu().numpy().view(np.uint8).reshape(h, w, 4), "depth": dep[b][k].cpu().numpy(),
+                   "hits": hit[b][k].cpu().numpy().reshape(-1, 4).copy().view(hiplib.HIT_DTYPE).reshape(h, w)}
+            _check(res, z, want[0], step)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.bind_outputs(None, None, None)
+        ctx.set_batch(1, 0)
+    finally:
+        ctx.close()
