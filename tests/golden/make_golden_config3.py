@@ -2,7 +2,7 @@
 """BASELINE.json config 3 -- the benchmark's own configuration: 8192^3 procedural SVO, 1920x1080, primary + 1 bounce,
 camera K1 -- rendered by the reference shader itself under llvmpipe (oracle/_ref/llvmpipe_ref, shader read from
 /root/reference at run time; 1.4 s per frame on the build container's 8 cores = 2.4 Mrays/s).  Also renderMode 2 (the
-reference's default) and the 4K / 5-segment / mirror frame of config 4.  Every STEP-th pixel in x and y of colour, depth
+reference's default), the 4K / 5-segment / mirror frame of config 4, and config 2 (2048^3, primary rays only).  Every STEP-th pixel in x and y of colour, depth
 and the first cast's hit record is kept (the 1.44 GB pool is not stored: the generator is deterministic, a CRC of the
 pool is kept to catch drift).  Runs only in the build container.   python tests/golden/make_golden_config3.py"""
 import os
@@ -23,20 +23,33 @@ SHADER = "/root/reference/src/shaders/svotrace.comp"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
 STEP = 8
 # name, width, height, camera, frameNumber, renderMode, path segments, mirror test (svotrace.comp:500-504 switched on)
+# config 2: 2048^3, 1920x1080, primary rays only (renderModes 1 and 3) -- its own pool
+CASES2 = [("c2_m1", 1920, 1080, "K1", 2, 1, 2, 0), ("c2_m3", 1920, 1080, "K1", 2, 3, 2, 0), ("c2_K0_m1", 1920, 1080, "K0", 2, 1, 2, 0)]
 CASES = [("c3_f2", 1920, 1080, "K1", 2, 0, 2, 0), ("c3_f57", 1920, 1080, "K1", 57, 0, 2, 0), ("c3_K0_f3", 1920, 1080, "K0", 3, 0, 2, 0),
          ("c3_m2", 1920, 1080, "K1", 2, 2, 2, 0), ("c4_f2", 3840, 2160, "K1", 2, 0, 5, 1)]
 
 
 def main():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    pool, _ = scene.build_scene(8192)
+    out = {"step": np.array([STEP])}
+    run(8192, CASES, out, "")
+    run(2048, CASES2, out, "2048_")
+    out["index"] = np.array([c[0] for c in CASES])
+    out["index2048"] = np.array([c[0] for c in CASES2])
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config3_8192.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path))
+
+
+def run(n, cases, out, prefix):
+    pool, _ = scene.build_scene(n)
     tmp = tempfile.mkdtemp(prefix="golden_c3_")
     pool.tofile(os.path.join(tmp, "pool.bin"))
-    out = {"pool_crc32": np.array([zlib.crc32(pool.tobytes())], dtype=np.uint32), "pool_size": np.array([pool.size]),
-           "step": np.array([STEP])}
+    out[prefix + "pool_crc32"] = np.array([zlib.crc32(pool.tobytes())], dtype=np.uint32)
+    out[prefix + "pool_size"] = np.array([pool.size])
     job = ["pool " + os.path.join(tmp, "pool.bin")]
     variant = (2, 0)
-    for name, w, h, camname, frame, mode, bounces, mirror in CASES:
+    for name, w, h, camname, frame, mode, bounces, mirror in cases:
         if (bounces, mirror) != variant:
             job += ["bounces %d" % bounces, "mirror %d" % mirror]
             variant = (bounces, mirror)
@@ -45,7 +58,7 @@ def main():
                 "render " + os.path.join(tmp, name)]
     r = subprocess.run([REF_BIN, SHADER], input=("\n".join(job) + "\n").encode(), capture_output=True)
     assert r.returncode == 0, r.stderr.decode()[-500:]
-    for name, w, h, camname, frame, mode, bounces, mirror in CASES:
+    for name, w, h, camname, frame, mode, bounces, mirror in cases:
         p = os.path.join(tmp, name)
         sub = (slice(0, h, STEP), slice(0, w, STEP))
         out[name + "/rgba"] = np.fromfile(p + ".rgba", dtype=np.uint8).reshape(h, w, 4)[sub].copy()
@@ -54,10 +67,6 @@ def main():
         out[name + "/cam"] = np.asarray(CAMERAS[camname], dtype=np.float32)
         out[name + "/meta"] = np.array([w, h, frame, mode, bounces, mirror], dtype=np.int32)
         print(name, "hits in the subsample", int((out[name + "/first_hit"][..., 0] != 0).sum()), "of", out[name + "/rgba"].shape[:2])
-    out["index"] = np.array([c[0] for c in CASES])
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config3_8192.npz")
-    np.savez_compressed(path, **out)
-    print("wrote", path, os.path.getsize(path))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
-"""BASELINE.json config 3 -- what bench.py measures: 8192^3 procedural SVO, 1920x1080, primary + 1 bounce -- and the 4K /
-5-segment / mirror frame of config 4, against the reference shader's own output at full size (llvmpipe golden of every
+"""BASELINE.json config 3 -- what bench.py measures: 8192^3 procedural SVO, 1920x1080, primary + 1 bounce -- the 4K /
+5-segment / mirror frame of config 4, and config 2 (2048^3, primary rays only), against the reference shader's own output at full size (llvmpipe golden of every
 8th pixel in x and y: tests/golden/make_golden_config3.py).  CPU leg: the oracle on the same pixels.  GPU leg: the HIP
 pipelines' full frames, sampled; for the persistent pipeline also as bench.py runs it (frames in flight, batched)."""
 import os
@@ -22,6 +22,15 @@ def pool8192():
     z = np.load(GOLD)
     pool, _ = scene.build_scene(8192)
     assert pool.size == int(z["pool_size"][0]) and zlib.crc32(pool.tobytes()) == int(z["pool_crc32"][0]), \
+        "scene generator drifted: regenerate tests/golden/config3_8192.npz"
+    return pool
+
+
+@pytest.fixture(scope="module")
+def pool2048():
+    z = np.load(GOLD)
+    pool, _ = scene.build_scene(2048)
+    assert pool.size == int(z["2048_pool_size"][0]) and zlib.crc32(pool.tobytes()) == int(z["2048_pool_crc32"][0]), \
         "scene generator drifted: regenerate tests/golden/config3_8192.npz"
     return pool
 
@@ -54,6 +63,33 @@ def test_config3_oracle_matches_reference_at_full_size(pool8192, name):
     w, h, frame, mode, bounces, mirror = _meta(z, name)
     res = oracle.render(pool8192, w, h, z[name + "/cam"], frame, mode, bounces=bounces, mirror_mask=mirror, xstep=step, ystep=step)
     _check(res, z, name, step)
+
+
+def test_config2_oracle_matches_reference_at_full_size(pool2048):
+    from oracle import oracle
+    z = np.load(GOLD)
+    step = int(z["step"][0])
+    for name in (str(n) for n in z["index2048"]):
+        w, h, frame, mode, bounces, mirror = _meta(z, name)
+        res = oracle.render(pool2048, w, h, z[name + "/cam"], frame, mode, xstep=step, ystep=step)
+        _check(res, z, name, step)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_config2_hip_matches_reference_at_full_size(pool2048, pipeline):
+    from svo_raytracer_amd import hiplib
+    z = np.load(GOLD)
+    step = int(z["step"][0])
+    ctx = hiplib.HipContext(0)
+    try:
+        ctx.set_pipeline(pipeline)
+        ctx.pool_upload(pool2048)
+        for name in (str(n) for n in z["index2048"]):
+            w, h, frame, mode, bounces, mirror = _meta(z, name)
+            _check(ctx.render(None, w, h, z[name + "/cam"], frame, mode), z, name, step)
+    finally:
+        ctx.close()
 
 
 @pytest.mark.gpu
