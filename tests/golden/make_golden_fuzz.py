@@ -15,7 +15,7 @@
 
 Runs only in the build container.  Output: tests/golden/fuzz_golden.npz (data only).
 
-  * hostile cameras and the smallest legal pools (hs_*).
+  * hostile cameras and the smallest legal pools (hs_*); degenerate image sizes (sz_*).
 
     python tests/golden/make_golden_fuzz.py
 """
@@ -41,6 +41,9 @@ PAD = 1 << 20
 
 
 def size_of(name):
+    if name.startswith("sz_"):                      # degenerate image sizes: sz_<W>x<H>_...
+        w, h = name.split("_")[1].split("x")
+        return int(w), int(h)
     return (40, 24) if name.startswith("hs_") else (56, 36)
 
 
@@ -134,6 +137,11 @@ def cases():
                 for fr in (2, 9):
                     cs.append(("pv_%s_b%d_r%d_%s_f%d" % (pk, bounces, mirror, cn, fr), pk, cams[cn].copy(), fr, 0,
                                dict(bounces=bounces, mirror=mirror)))
+    # degenerate image sizes (1x1, single rows and columns, sizes around the 8-pixel work group)
+    pools["s64"] = scene.build_scene(64)[0]
+    for w, h in ((1, 1), (1, 37), (53, 1), (3, 3), (4, 4), (5, 9), (7, 8), (8, 7), (9, 9), (15, 17), (64, 3), (2, 130), (1000, 2), (3, 777)):
+        cs.append(("sz_%dx%d_K1_m0" % (w, h), "s64", cams["K1"].copy(), 2, 0))
+        cs.append(("sz_%dx%d_K0_m2" % (w, h), "s64", cams["K0"].copy(), 3, 2))
     return pools, cs
 
 

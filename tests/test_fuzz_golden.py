@@ -36,7 +36,7 @@ def _golden(name):
 
 def test_fixture_is_what_the_generator_describes():
     cases = _cases()
-    assert len(cases) >= 360
+    assert len(cases) >= 390
     assert sum(1 for n, _ in cases if n.startswith("pv_")) == 40
     assert {pk[0] for _, pk in cases} == {"f", "m", "s", "t"}   # fuzz, mangled, scene, tiny
     assert {int(_z()[n + "/meta"][2]) for n, _ in cases} >= {2147483647, -2147483648, 16777216}
