@@ -161,6 +161,18 @@ int svo_set_progressive(svo_ctx *ctx, int enabled);
  * on a full 1080p frame, 1.5x on the 1/8 frame of an 8-GPU split.  The bytes of every frame are those of a dispatch of
  * its own.  nframes = 1 (default) = the reference's one dispatch per frame.  svo_count_frame counts the first frame. */
 int svo_set_batch(svo_ctx *ctx, int nframes, uint64_t frame_stride);
+/* The interior-descriptor table: a derived acceleration copy of the pool inside the library ("a derived
+ * acceleration copy inside the library is allowed, results must not change").  The shader fetches a child record in
+ * every iteration only to learn "empty?" (svotrace.comp:295) and "leaf?" (:311); the table keeps those two bits of all
+ * eight children in an 8-byte descriptor of the PARENT, so that only a descend loads (one aligned descriptor) and the
+ * pool's records are read once per cast, for the node it ends on.  Built on the GPU at the first dispatch after a pool
+ * change (svo_pool_upload / _update / builders), walked by pipeline 1.  mode 1 (default): use it when the pool can be
+ * derived (up to 13 levels, unrolling within budget -- anything a builder produces); otherwise, and with mode 0, the
+ * records are walked as the shader does.  Same bytes either way. */
+int svo_set_derived(svo_ctx *ctx, int mode);
+/* builds the table if the pool changed; *descriptors = its entries, *bytes = device memory it holds, *walkable = 1 if
+ * pipeline 1 walks it (0 = the pool is not derivable), *build_ms = GPU time of the last build.  Any may be NULL. */
+int svo_derived_info(svo_ctx *ctx, uint64_t *descriptors, uint64_t *bytes, int *walkable, float *build_ms);
 /* record per-pixel svo_hit (costs 16 B/pixel of stores); default on */
 int svo_set_hit_records(svo_ctx *ctx, int enabled);
 

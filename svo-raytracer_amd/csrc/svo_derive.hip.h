@@ -1,0 +1,250 @@
+// svo_derive.hip.h -- the interior-descriptor table: a derived acceleration copy of the pool.
+//
+// What the reference does per iteration (svotrace.comp:286-313): fetch the child record, then look at its value
+// byte (empty?), its tag (from the parent's leafMask) and its child pointer (leaf?).  48 % of the iterations are
+// ADVANCEs that only needed "is this child empty", and every HIT needs nothing but "non-empty, no child block" -- the
+// reference's layout keeps those two bits inside the child, so a cast pays a dependent, unaligned 7-byte fetch per
+// iteration.  SURVEY 8(b) allows "a derived acceleration copy inside the library, results must not change": this is it.
+//
+// One 8-byte descriptor per PARENT STATE of the traversal, i.e. per pair (B = child-block base, M = tag mask) the
+// walk can hold (svotrace.comp:291: extractChild(parent.descriptor, parent.childPointer, ..., parent.leafMask) is a
+// function of exactly that pair):
+//   desc[i] = { byte offset of the descriptor of its first child that has a child block,
+//               ne | has << 8 }      ne bit c: child c's value byte != 0            (svotrace.comp:295)
+//                                    has bit c: child c is tag 0 with a non-zero cp  (svotrace.comp:311, extractNode)
+//   aux[i]  = { B, M }               only read after the loop: hit pointer = B + offset(c, M) (svotrace.comp:381)
+// Children with a child block get consecutive descriptors (rank among the `has` bits), so DESCEND is
+// desc + 8 * popcount(has & below(c)); ADVANCE and HIT touch no memory at all; POP re-reads the ancestor's descriptor
+// (the LDS stack entry shrinks to {descriptor offset, t_max}).
+//
+// The table is an unrolling of the pool from the root pair, level by level (13 levels: a 13-level pool is the
+// reference's limit, MAX_DEPTH), so it states exactly what the byte walk would read -- also for pools no builder
+// produces (children that overlap, point backwards, lie past the end: reads there give 0 through the same buffer
+// descriptor the byte walk uses).  Descriptor 0 is the pair (0, 0) that a POP to a never-pushed stack level restores
+// (the reference's zero-initialised octstack): its children are the records at bytes 0, 7, .., 49 read as interior
+// nodes; where those are the root / the root's children their descriptors are shared, otherwise unrolled as well.
+// A pool that is still interior at level 13, or whose unrolling outgrows the budget (cycles), is left to the byte walk
+// (Table::ok = false): every result stays the reference's either way.
+#pragma once
+#include "svo_build.hip.h"
+#include "svo_trav.h"
+
+namespace svo {
+namespace derive {
+
+constexpr uint32_t kPhantom = 0u, kRoot = 1u;
+constexpr int kLevels = kMaxDepth;   // parent states at depth 0..12
+
+struct Table {
+  uint2 *desc = nullptr;
+  uint2 *aux = nullptr;
+  uint32_t count = 0;      // descriptors
+  size_t cap = 0;          // allocated descriptors
+  bool ok = false;         // the persistent pipeline may walk it
+  int levels = 0;
+  float build_ms = 0.0f;
+};
+
+inline void free_table(Table &t) {
+  if (t.desc) (void)hipFree(t.desc);
+  if (t.aux) (void)hipFree(t.aux);
+  t = Table();
+}
+
+// child c of the parent state (B, M): is it non-empty, does it have a child block, and which state is it as a parent
+__device__ __forceinline__ void child_of(const BufPool &pool, uint32_t B, uint32_t M, uint32_t c, bool &ne, bool &has, uint2 &key) {
+  const uint32_t tag = (M >> (2u * c)) & 3u;
+  const uint32_t ptr = B + child_offset(M, c);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pool.rsrc, (int)ptr, 0, 0);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pool.rsrc, (int)(ptr + 4u), 0, 0);
+  ne = (lo & 0xffu) != 0u;
+  const uint32_t cp = tag == 0u ? rec2_cp(lo, hi) : 0u;
+  has = cp != 0u;
+  key = make_uint2(ptr + cp, rec2_mask_be(hi));
+}
+
+// pass 1 over the parent states [lo, lo + n): the ne / has bits of their eight children
+__global__ __launch_bounds__(256) void masks_kernel(const uint8_t *pool_base, uint32_t pool_len, const uint2 *aux, uint32_t lo,
+                                                    uint32_t n, uint16_t *masks, uint8_t *hasmask) {
+  const BufPool pool = make_bufpool(pool_base, pool_len);
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x, i = t >> 3, c = t & 7u;
+  bool ne = false, has = false;
+  if (i < n) {
+    const uint2 k = aux[lo + i];
+    uint2 ck;
+    child_of(pool, k.x, k.y & 0xffffu, c, ne, has, ck);
+  }
+  const unsigned long long bn = __ballot(ne), bh = __ballot(has);
+  if (i < n && c == 0u) {
+    const uint32_t sh = threadIdx.x & 56u;
+    const uint32_t m_ne = (uint32_t)(bn >> sh) & 0xffu, m_has = (uint32_t)(bh >> sh) & 0xffu;
+    masks[i] = (uint16_t)(m_ne | (m_has << 8));
+    hasmask[i] = (uint8_t)m_has;
+  }
+}
+
+// pass 2: descriptors of [lo, lo + n); the states of their children with a child block are appended from `next` on
+__global__ __launch_bounds__(256) void place_kernel(const uint8_t *pool_base, uint32_t pool_len, uint2 *aux, uint2 *desc,
+                                                    uint32_t lo, uint32_t n, const uint16_t *masks, const uint32_t *first,
+                                                    uint32_t next, uint32_t cap, int last_level) {
+  const BufPool pool = make_bufpool(pool_base, pool_len);
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x, i = t >> 3, c = t & 7u;
+  if (i >= n) return;
+  const uint32_t m = masks[i], has = m >> 8;
+  const uint32_t base = next + first[i];
+  if (c == 0u) desc[lo + i] = make_uint2(last_level ? 0u : base * 8u, m);
+  if (last_level || !((has >> c) & 1u)) return;
+  const uint32_t j = base + (uint32_t)__builtin_popcount(has & ((1u << c) - 1u));
+  if (j >= cap) return;
+  const uint2 k = aux[lo + i];
+  bool ne, hs;
+  uint2 ck;
+  child_of(pool, k.x, k.y & 0xffffu, c, ne, hs, ck);
+  aux[j] = ck;
+}
+
+struct Scratch {
+  uint16_t *masks = nullptr;
+  uint8_t *hasmask = nullptr;
+  uint32_t *first = nullptr;
+  size_t cap = 0;
+};
+
+// Expand the states [lo, lo + n): returns how many child states were appended at `next` (0xffffffff on overflow of the
+// budget); with last_level set nothing is appended and the return value is the number of children that WOULD have
+// been (non-zero = the pool is deeper than the table).
+inline uint32_t expand(build::Builder &B, Table &t, const uint8_t *pool, uint32_t pool_len, uint32_t lo, uint32_t n, uint32_t next,
+                       bool last_level) {
+  if (n == 0) return 0;
+  uint16_t *masks = B.alloc<uint16_t>(n);
+  uint8_t *hasmask = B.alloc<uint8_t>(n);
+  uint32_t *first = B.alloc<uint32_t>(n);
+  if (!B.ok()) return 0xffffffffu;
+  const unsigned grid = (unsigned)(((size_t)n * 8 + 255) / 256);
+  hipLaunchKernelGGL(masks_kernel, dim3(grid), dim3(256), 0, B.stream, pool, pool_len, t.aux, lo, n, masks, hasmask);
+  uint32_t total = 0;
+  B.exclusive_scan<uint8_t, true>(hasmask, first, n, &total);
+  if (!B.ok()) return 0xffffffffu;
+  if (!last_level && (uint64_t)next + total > t.cap) return 0xffffffffu;
+  hipLaunchKernelGGL(place_kernel, dim3(grid), dim3(256), 0, B.stream, pool, pool_len, t.aux, t.desc, lo, n, masks, first, next,
+                     (uint32_t)t.cap, last_level ? 1 : 0);
+  return total;
+}
+
+// (Re)build the table for the pool.  hipSuccess with t.ok = false means "not derivable, use the byte walk".
+inline hipError_t build_table(Table &t, const uint8_t *d_pool, uint64_t pool_len64, hipStream_t stream) {
+  const uint32_t pool_len = (uint32_t)pool_len64;
+  t.ok = false; t.count = 0; t.levels = 0;
+  // budget: a proper tree has one state per interior node with a child block (>= 7 + 8 bytes of pool each)
+  const size_t want = (size_t)pool_len / 8 + 4096;
+  if (want >= (1u << 28)) return hipSuccess;   // descriptor byte offsets must fit 31 bits
+  hipError_t e;
+  if (t.cap < want || t.cap > 4 * want) {
+    if (t.desc) (void)hipFree(t.desc);
+    if (t.aux) (void)hipFree(t.aux);
+    t.desc = nullptr; t.aux = nullptr; t.cap = 0;
+    if ((e = hipMalloc((void **)&t.desc, want * sizeof(uint2))) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&t.aux, want * sizeof(uint2))) != hipSuccess) return e;
+    t.cap = want;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, stream);
+  build::Builder B;
+  B.stream = stream;
+  // the first 64 bytes of the pool on the host: the root record and the records the phantom state sees
+  uint8_t head[64];
+  if ((e = hipMemcpyAsync(head, d_pool, 64, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  for (uint32_t i = 0; i < 64; i++) if (i >= pool_len) head[i] = 0;
+  auto rec_key = [&](uint32_t at, bool &ne, bool &has) {   // the record at byte `at`, read as an interior node
+    ne = head[at] != 0;
+    const uint32_t cp = ((uint32_t)head[at + 1] << 24) | ((uint32_t)head[at + 2] << 16) | ((uint32_t)head[at + 3] << 8) | head[at + 4];
+    has = cp != 0;
+    return make_uint2(at + cp, ((uint32_t)head[at + 5] << 8) | head[at + 6]);
+  };
+  bool ne0, has0;
+  const uint2 seeds[2] = {make_uint2(0u, 0u), rec_key(0, ne0, has0)};   // phantom, root (svotrace.comp:222)
+  if ((e = hipMemcpyAsync(t.aux, seeds, sizeof seeds, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+
+  bool ok = true;
+  uint32_t lo = kRoot, n = 1, end = 2;
+  int depth = 0;
+  for (; depth < kLevels && n > 0; depth++) {
+    const bool last = depth == kLevels - 1;
+    const uint32_t got = expand(B, t, d_pool, pool_len, lo, n, end, last);
+    if (got == 0xffffffffu) { ok = false; break; }
+    if (last) { if (got) ok = false; break; }
+    lo = end; n = got; end += got;
+  }
+  t.levels = depth + (n > 0 ? 1 : 0);
+  if (B.ok() && ok) {
+    // the phantom state (0, 0): children = the records at 0, 7, .., 49 read as interior nodes
+    uint2 rootd, rootkids_aux[8], rootkids_desc[8];
+    if ((e = hipMemcpyAsync(&rootd, t.desc + kRoot, sizeof rootd, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    const uint32_t nkids = (uint32_t)__builtin_popcount((rootd.y >> 8) & 0xffu), kid0 = rootd.x / 8u;
+    if (nkids) {
+      if ((e = hipMemcpyAsync(rootkids_aux, t.aux + kid0, nkids * sizeof(uint2), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(rootkids_desc, t.desc + kid0, nkids * sizeof(uint2), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    }
+    uint32_t m_ne = 0, m_has = 0, nph = 0;
+    uint2 ph_aux[8], ph_desc[8];
+    bool ph_known[8];
+    for (uint32_t c = 0; c < 8; c++) {
+      bool ne, has;
+      const uint2 key = rec_key(7u * c, ne, has);
+      if (ne) m_ne |= 1u << c;
+      if (!has) continue;
+      m_has |= 1u << c;
+      ph_aux[nph] = key; ph_known[nph] = false;
+      if (key.x == seeds[1].x && key.y == seeds[1].y) { ph_desc[nph] = rootd; ph_known[nph] = true; }
+      for (uint32_t k = 0; k < nkids && !ph_known[nph]; k++)
+        if (key.x == rootkids_aux[k].x && key.y == (rootkids_aux[k].y & 0xffffu)) { ph_desc[nph] = rootkids_desc[k]; ph_known[nph] = true; }
+      if (!ph_known[nph]) ph_desc[nph] = make_uint2(0u, 0u);
+      nph++;
+    }
+    if ((uint64_t)end + nph > t.cap) ok = false;
+    if (ok) {
+      const uint2 phd = make_uint2(end * 8u, m_ne | (m_has << 8));
+      if ((e = hipMemcpyAsync(t.desc + kPhantom, &phd, sizeof phd, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+      if (nph) {
+        if ((e = hipMemcpyAsync(t.aux + end, ph_aux, nph * sizeof(uint2), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(t.desc + end, ph_desc, nph * sizeof(uint2), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+      }
+      const uint32_t ph0 = end;
+      end += nph;
+      // children of the phantom that are neither the root nor one of its children: unrolled like the root
+      uint32_t lo2 = end;
+      for (uint32_t k = 0; k < nph && ok; k++) {
+        if (ph_known[k]) continue;
+        const uint32_t got = expand(B, t, d_pool, pool_len, ph0 + k, 1, end, false);
+        if (got == 0xffffffffu) { ok = false; break; }
+        end += got;
+      }
+      uint32_t n2 = end - lo2;
+      for (int d = 2; d < kLevels && n2 > 0 && ok; d++) {
+        const bool last = d == kLevels - 1;
+        const uint32_t got = expand(B, t, d_pool, pool_len, lo2, n2, end, last);
+        if (got == 0xffffffffu) { ok = false; break; }
+        if (last) { if (got) ok = false; break; }
+        lo2 = end; n2 = got; end += got;
+      }
+    }
+  }
+  (void)hipEventRecord(e1, stream);
+  e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = B.err;
+  if (e == hipSuccess) e = hipGetLastError();
+  (void)hipEventElapsedTime(&t.build_ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  B.release();
+  if (e != hipSuccess) return e;
+  t.count = end;
+  t.ok = ok;
+  return hipSuccess;
+}
+
+}  // namespace derive
+}  // namespace svo

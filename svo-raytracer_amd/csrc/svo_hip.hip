@@ -15,6 +15,7 @@
 #include "svo_wavefront.hip.h"
 #include "svo_build.hip.h"
 #include "svo_beam.hip.h"
+#include "svo_derive.hip.h"
 
 using namespace svo;
 
@@ -58,6 +59,11 @@ struct svo_ctx {
   unsigned beam_frames = 0;
   uint8_t *d_beam_live = nullptr;   // which nodes of the pool's top levels a cast can end in or below (svo_beam.hip.h)
   bool beam_live_valid = false;     // cleared by everything that changes the pool
+  // interior-descriptor table of the pool (svo_derive.hip.h): rebuilt lazily after every pool change, walked by the
+  // persistent pipeline when the pool is derivable
+  derive::Table dt;
+  bool derived_valid = false;     // cleared by everything that changes the pool
+  int derived_mode = 1;           // 0 = always walk the records, 1 = walk the table when there is one
   WavefrontBuffers wf;
   PersistBuffers pb;
   svo_stats stats{};
@@ -122,6 +128,7 @@ int svo_destroy(svo_ctx *c) {
   if (c->d_counters) (void)hipFree(c->d_counters);
   for (auto &e : c->beam_done) if (e) (void)hipEventDestroy(e);
   if (c->d_beam_live) (void)hipFree(c->d_beam_live);
+  derive::free_table(c->dt);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -157,7 +164,7 @@ static int refresh_dword0(svo_ctx *c) {
 }
 
 int svo_pool_reserve(svo_ctx *c, uint64_t nbytes) {
-  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
@@ -170,7 +177,7 @@ int svo_pool_reserve(svo_ctx *c, uint64_t nbytes) {
 }
 
 int svo_pool_upload_device(svo_ctx *c, const void *dptr, uint64_t nbytes) {
-  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || (!dptr && nbytes)) return fail(c, SVO_E_INVALID, "svo_pool_upload_device: null buffer");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
@@ -183,7 +190,7 @@ int svo_pool_upload_device(svo_ctx *c, const void *dptr, uint64_t nbytes) {
 }
 
 int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
-  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || (!host && nbytes)) return fail(c, SVO_E_INVALID, "svo_pool_upload: null buffer");
   HIPCHK(c, hipSetDevice(c->device));
   // frames may be in flight on any stream the caller has handed over (svo_set_stream): the pool changes only
@@ -199,7 +206,7 @@ int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
 }
 
 int svo_pool_update(svo_ctx *c, const void *host_base, uint64_t start, uint64_t end) {
-  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || !host_base) return fail(c, SVO_E_INVALID, "svo_pool_update: null buffer");
   if (start >= end) return fail(c, SVO_E_INVALID, "Update SSBO error: Invalid parameters.");
   if (!c->d_pool) return fail(c, SVO_E_NOPOOL, "svo_pool_update before svo_pool_upload");
@@ -226,7 +233,7 @@ int svo_pool_download(svo_ctx *c, void *host, uint64_t nbytes) {
 }
 
 int svo_pool_device_ptr(svo_ctx *c, void **dptr, uint64_t *nbytes) {
-  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || !dptr) return SVO_E_INVALID;
   *dptr = c->d_pool;
   if (nbytes) *nbytes = c->pool_len;
@@ -247,7 +254,7 @@ __global__ void count_zero_bytes_kernel(const uint8_t *p, size_t n, unsigned int
 }
 
 int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *material, int n, uint64_t *out_nbytes) {
-  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || !height || !material) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: null map");
   if (n < 8 || n > 8192 || (n & (n - 1))) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: n must be a power of two in 8..8192");
   HIPCHK(c, hipSetDevice(c->device));
@@ -287,7 +294,7 @@ int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *
 }
 
 int svo_build_from_voxels(svo_ctx *c, const uint8_t *voxels, int n, uint64_t *out_nbytes) {
-  if (c) c->beam_live_valid = false;   // the pool is about to change (or to be handed out for writing)
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || !voxels) return fail(c, SVO_E_INVALID, "svo_build_from_voxels: null grid");
   if (n < 2 || n > 1024 || (n & (n - 1))) return fail(c, SVO_E_INVALID, "svo_build_from_voxels: n must be a power of two in 2..1024");
   HIPCHK(c, hipSetDevice(c->device));
@@ -392,6 +399,27 @@ int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_sixteenths)
   c->pb.thresh_num = round_threshold_sixteenths ? round_threshold_sixteenths : 9;
   c->wf.waves_per_cu = waves_per_cu;
   c->wf.thresh_num = round_threshold_sixteenths ? round_threshold_sixteenths : 12;
+  return SVO_OK;
+}
+
+static int ensure_derived(svo_ctx *c);
+
+int svo_set_derived(svo_ctx *c, int mode) {
+  if (!c || mode < 0 || mode > 1) return fail(c, SVO_E_INVALID, "svo_set_derived: 0 (records) or 1 (descriptor table)");
+  c->derived_mode = mode;
+  return SVO_OK;
+}
+
+int svo_derived_info(svo_ctx *c, uint64_t *descriptors, uint64_t *bytes, int *walkable, float *build_ms) {
+  if (!c) return SVO_E_INVALID;
+  if (!c->d_pool || c->pool_len < 7) return fail(c, SVO_E_NOPOOL, "svo_derived_info: no pool uploaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_derived(c);
+  if (rc) return rc;
+  if (descriptors) *descriptors = c->dt.count;
+  if (bytes) *bytes = (uint64_t)c->dt.cap * 2 * sizeof(uint2);
+  if (walkable) *walkable = c->dt.ok ? 1 : 0;
+  if (build_ms) *build_ms = c->dt.build_ms;
   return SVO_OK;
 }
 
@@ -515,6 +543,18 @@ static int launch_beam(svo_ctx *c, Frame &f, int &set) {
 
 static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *color, float *depth, uint4 *hits);
 
+// The descriptor table follows the pool: (re)built at the first dispatch after a pool change.  Every pool mutator has
+// synchronised the device, except a caller writing through svo_pool_device_ptr -- so wait for the device here too: no
+// frame in flight may still read the table that is replaced.
+static int ensure_derived(svo_ctx *c) {
+  if (c->derived_valid) return SVO_OK;
+  HIPCHK(c, hipDeviceSynchronize());
+  hipError_t e = derive::build_table(c->dt, c->d_pool, c->pool_len, c->stream);
+  if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("descriptor table: ") + hipGetErrorString(e));
+  c->derived_valid = true;
+  return SVO_OK;
+}
+
 static int launch_frame(svo_ctx *c, bool count) {
   Frame f;
   int rc = make_frame(c, f);
@@ -555,7 +595,12 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
   int rc = SVO_OK;
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
   if (c->pipeline == 1 && !count) {
-    rc = persist_launch(c->pb, c->d_pool, f, color, depth, hits, out_elems(c, f), c->stream);
+    static const int env_mode = getenv("SVO_DERIVED") ? atoi(getenv("SVO_DERIVED")) : -1;   // A/B override
+    const int mode = env_mode >= 0 ? env_mode : c->derived_mode;
+    if (mode != 0 && (rc = ensure_derived(c)) != SVO_OK) return rc;
+    const bool walk_table = mode != 0 && c->dt.ok;   // not derivable (deeper than 13 levels, cyclic): the records are walked
+    rc = persist_launch(c->pb, c->d_pool, f, color, depth, hits, out_elems(c, f), c->stream, walk_table ? c->dt.desc : nullptr,
+                        walk_table ? c->dt.aux : nullptr, walk_table ? c->dt.count : 0u);
     if (rc) return fail(c, SVO_E_HIP, std::string("persistent pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }

@@ -22,6 +22,7 @@
 #include "svo_fused.hip.h"
 #include "svo_trav.h"
 #include "svo_travloop.h"
+#include "svo_travloop2.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -51,6 +52,10 @@ struct PersistArgs {
   int fold;          // samples per pixel carried by this launch (see persist_launch); 1 = one launch per sample
   int group;         // fold > 1: tiles per group of a band's walk (sample by sample inside a group)
   int thresh_num;    // a round starts once active lanes <= thresh_num/16 of those active at its start
+  // interior-descriptor table (svo_derive.hip.h); only read by the kDerived kernels
+  const uint2 *desc;
+  const uint2 *aux;
+  uint32_t desc_count;
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -86,20 +91,106 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
   if (a.sample == 0 && smp == 0u) a.depth[pix] = depth;
 }
 
-// SVO_ASM_LOOP=1 (default): the trips run in trav_loop() (svo_travloop.h, gfx950 assembly);
-// SVO_ASM_LOOP=0: hipcc's translation of trav_step() -- same results, kept for A/B runs and as the readable form.
+// SVO_ASM_LOOP=1 (default): the trips run in trav_loop() / trav_loop2() (gfx950 assembly);
+// SVO_ASM_LOOP=0: hipcc's translation of trav_step() / trav_step2() -- same results, kept for A/B runs and as the
+// readable form.
 #ifndef SVO_ASM_LOOP
 #define SVO_ASM_LOOP 1
 #endif
+
+// How a cast reads the octree.  ByteWalk: the reference's records, one fetched per iteration (svo_trav.h).
+// DescWalk: the interior-descriptor table derived from them (svo_derive.hip.h, svo_trav2.h); the pool itself is only
+// read for the record of the node a cast ends on.
+struct ByteWalk {
 #if SVO_ASM_LOOP
-#define SVO_TRAV_T TravRegs
-#define SVO_TRAV_INIT trav_init_regs
-#define SVO_TRAV_RESULT(t, s) trav_result_regs(pool, t, s)
+  typedef TravRegs State;
 #else
-#define SVO_TRAV_T Trav
-#define SVO_TRAV_INIT trav_init
-#define SVO_TRAV_RESULT(t, s) trav_result(t, s)
+  typedef Trav State;
 #endif
+  typedef WaveStack Stack;
+  BufPool pool;
+  uint64_t root;
+  __device__ __forceinline__ void setup(const PersistArgs &a) {
+    pool = make_bufpool(a.pool, a.f.pool_len);
+    root = load_record(pool, 0u);
+  }
+  __device__ __forceinline__ int init(State &t, V3 o, V3 d, bool cone, float t_start = 0.0f) const {
+#if SVO_ASM_LOOP
+    return trav_init_regs(root, t, o, d, cone, t_start);
+#else
+    return trav_init(root, t, o, d, cone, t_start);
+#endif
+  }
+  __device__ __forceinline__ Cast result(const State &t, int status) const {
+#if SVO_ASM_LOOP
+    return trav_result_regs(pool, t, status);
+#else
+    return trav_result(t, status);
+#endif
+  }
+  // trips until at most `threshold` of the lanes in `act` are still traversing
+  __device__ __forceinline__ void run(Stack &stk, uint32_t lane, State &t, int &status, unsigned long long act, int threshold,
+                                      unsigned long long cone_lanes, uint32_t *mix) const {
+#if SVO_ASM_LOOP
+    trav_loop(pool, stk, lane, t, status, act, threshold, cone_lanes, mix);
+#else
+    (void)act; (void)cone_lanes; (void)mix;
+    for (;;) {
+#ifdef SVO_STAMPS
+      unsigned long long st_load = 0;
+      if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t, st_load);
+#else
+      if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t);
+#endif
+      if (__builtin_popcountll(__ballot(status == ST_ACTIVE)) <= threshold) break;
+    }
+#endif
+  }
+};
+
+struct DescWalk {
+#if SVO_ASM_LOOP
+  typedef TravRegs2 State;
+#else
+  typedef Trav2 State;
+#endif
+  typedef WaveStack2 Stack;
+  BufPool pool;
+  DescTab tab;
+  uint2 rootd;
+  __device__ __forceinline__ void setup(const PersistArgs &a) {
+    pool = make_bufpool(a.pool, a.f.pool_len);
+    tab = make_desctab(a.desc, a.aux, a.desc_count);
+    const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(tab.rsrc, (int)kDescRoot, 0, 0);
+    rootd = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)r.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y));
+  }
+  __device__ __forceinline__ int init(State &t, V3 o, V3 d, bool cone, float t_start = 0.0f) const {
+#if SVO_ASM_LOOP
+    return trav_init_regs2(rootd, t, o, d, cone, t_start);
+#else
+    return trav_init2(rootd, t, o, d, cone, t_start);
+#endif
+  }
+  __device__ __forceinline__ Cast result(const State &t, int status) const {
+#if SVO_ASM_LOOP
+    return trav_result_regs2(pool, tab, t, status);
+#else
+    return trav_result2(pool, tab, t, status);
+#endif
+  }
+  __device__ __forceinline__ void run(Stack &stk, uint32_t lane, State &t, int &status, unsigned long long act, int threshold,
+                                      unsigned long long cone_lanes, uint32_t *mix) const {
+#if SVO_ASM_LOOP
+    trav_loop2(tab, stk, lane, t, status, act, threshold, cone_lanes, mix);
+#else
+    (void)act; (void)cone_lanes; (void)mix;
+    for (;;) {
+      if (status == ST_ACTIVE) status = trav_step2(tab, stk, lane, t);
+      if (__builtin_popcountll(__ballot(status == ST_ACTIVE)) <= threshold) break;
+    }
+#endif
+  }
+};
 
 #ifndef SVO_BAND_COLMAJOR
 #define SVO_BAND_COLMAJOR 1
@@ -116,17 +207,23 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
 #ifndef SVO_PERSIST_WAVES_PER_SIMD
 #define SVO_PERSIST_WAVES_PER_SIMD 5
 #endif
-template <int kMode>
-__global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel(const PersistArgs a) {
-  __shared__ WaveStack stk;
+#ifndef SVO_DERIVED_WAVES_PER_SIMD
+#define SVO_DERIVED_WAVES_PER_SIMD 6
+#endif
+template <class Walk> struct WalkWaves { static constexpr int value = SVO_PERSIST_WAVES_PER_SIMD; };
+template <> struct WalkWaves<DescWalk> { static constexpr int value = SVO_DERIVED_WAVES_PER_SIMD; };
+
+template <int kMode, class Walk>
+__global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(const PersistArgs a) {
+  __shared__ typename Walk::Stack stk;
   const uint32_t lane = threadIdx.x;
   const Frame &f = a.f;
-  const BufPool pool = make_bufpool(a.pool, f.pool_len);
-  const uint64_t root = load_record(pool, 0u);
+  Walk walk;
+  walk.setup(a);
   const V3 cam_o = mk(f.cam[0], f.cam[1], f.cam[2]);
   const V3 sun2 = normalize3(mk(0.5f, 0.5f, 0.5f));
 
-  SVO_TRAV_T t;
+  typename Walk::State t;
   int status = ST_IDLE;
   uint32_t pix = 0, seg = 0;   // seg: path segment in the low byte; a.fold > 1: sample index in bits 8..23, frame of the batch above
   int px = 0, py = 0;
@@ -147,7 +244,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
     if (status >= ST_HIT) {
-      const Cast c = SVO_TRAV_RESULT(t, status);
+      const Cast c = walk.result(t, status);
       status = ST_IDLE;
       const uint32_t segn = seg & 0xffu, smp = seg >> 8;   // smp: sample | frame of the batch << 16
       if (segn == 0u && (smp & 0xffffu) == 0u && f.write_hits && a.sample == 0) {
@@ -179,7 +276,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             } else {
               d = nd;
               seg++;
-              status = SVO_TRAV_INIT(root, t, vpos, nd, true);
+              status = walk.init(t, vpos, nd, true);
             }
           } else {
             const V3 sun = normalize3(mk(1.0f, 1.0f, 1.0f));
@@ -211,7 +308,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
             mask = mc;
             depth = c.t;
             seg = (seg & ~0xffu) | 1u;
-            status = SVO_TRAV_INIT(root, t, c.voxel_pos, sun2, false);
+            status = walk.init(t, c.voxel_pos, sun2, false);
           } else {
             persist_emit(a, pix, smp, px, py, sky_colour(d), 0.0f);
           }
@@ -316,7 +413,7 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
 #else
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
 #endif
-            status = SVO_TRAV_INIT(root, t, cam_o, d, false, beam_start(f, px, py));
+            status = walk.init(t, cam_o, d, false, beam_start(f, px, py));
             if (kMode == 4) status = ST_MISS;   // no cast: straight to the (black) pixel
           }
         }
@@ -349,31 +446,17 @@ __global__ __launch_bounds__(64, SVO_PERSIST_WAVES_PER_SIMD) void persist_kernel
     // not wait for the longest cast of the wave (SVO_DRAIN_NUM/16 of the active lanes may still be traversing; 0 = wait for all)
     const int drained = (active0 * SVO_DRAIN_NUM) / 16 < active0 - 1 ? (active0 * SVO_DRAIN_NUM) / 16 : (active0 > 0 ? active0 - 1 : 0);
     const int threshold = __builtin_amdgcn_readfirstlane(bands_left > 0 ? (active0 * a.thresh_num) / 16 : drained);
-#if SVO_ASM_LOOP
     {
       const unsigned long long act = __ballot(status == ST_ACTIVE);
       // cone rays: the secondary segments of a GI path (svotrace.comp:446: coneTrace = i != 0)
-      trav_loop(pool, stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold),
-                kMode == 0 ? __ballot((seg & 0xffu) != 0u) : 0ull
 #ifdef SVO_STAMPS
-                , st_mix
-#endif
-                );
-    }
+      uint32_t *const mixp = st_mix;
 #else
-    for (;;) {
-#ifdef SVO_STAMPS
-      if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t, st_load);
-#else
-      if (status == ST_ACTIVE) status = trav_step(pool, stk, lane, t);
+      uint32_t *const mixp = nullptr;
 #endif
-      const int active = __builtin_popcountll(__ballot(status == ST_ACTIVE));
-#ifdef SVO_STAMPS
-      st_ntrip++;
-#endif
-      if (active <= threshold) break;
+      walk.run(stk, lane, t, status, act, __builtin_amdgcn_readfirstlane(threshold),
+               kMode == 0 ? __ballot((seg & 0xffu) != 0u) : 0ull, mixp);
     }
-#endif
 #ifdef SVO_STAMPS
     { const unsigned long long now = __builtin_readcyclecounter(); st_trav += now - st_t0; st_t0 = now; }
 #endif
@@ -413,7 +496,7 @@ struct PersistBuffers {
   int blocks = 0;
   int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/history/sweep8.sh)
   int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
-  int max_per_cu = 16, cus = 256;
+  int max_per_cu = 16, max_per_cu_desc = 16, cus = 256;   // resident waves per CU: byte walk / descriptor walk
   unsigned launches = 0, frames = 0;
 };
 
@@ -429,7 +512,8 @@ inline void persist_free(PersistBuffers &b) {
 
 template <int kMode>
 inline void persist_launch_mode(const PersistArgs &a, int blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(persist_kernel<kMode>, dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  if (a.desc) hipLaunchKernelGGL((persist_kernel<kMode, DescWalk>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((persist_kernel<kMode, ByteWalk>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
 }
 
 __global__ void persist_resolve_kernel(const Frame f, const float *facc, size_t npix, uint32_t *color) {
@@ -459,8 +543,10 @@ __global__ __launch_bounds__(64) void persist_resolve_tiles_kernel(const Frame f
 
 // `out_npix` = elements of the output images: W*H, or more when packed stripes overhang the frame (caller-owned
 // gather buffers); the colour-sum planes are indexed like the outputs.
+// `desc` / `aux` / `desc_count`: the interior-descriptor table of the pool (svo_derive.hip.h), or null = walk the records
 inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f, uint32_t *color, float *depth,
-                          uint4 *hits, size_t out_npix, hipStream_t stream) {
+                          uint4 *hits, size_t out_npix, hipStream_t stream, const uint2 *desc = nullptr,
+                          const uint2 *aux = nullptr, uint32_t desc_count = 0) {
   // the colour-sum planes are indexed like the outputs: a batch needs room for all its frames
   const size_t npix = f.batch > 1 ? std::max(out_npix, (size_t)f.batch * (size_t)f.frame_stride) : out_npix;
   hipError_t e;
@@ -473,16 +559,19 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     int dev = 0, cus = 256, per_cu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel<0>, 64, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel<0, ByteWalk>, 64, 0) != hipSuccess || per_cu < 1)
       per_cu = 16;
     b.max_per_cu = per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel<0, DescWalk>, 64, 0) != hipSuccess || per_cu < 1)
+      per_cu = 16;
+    b.max_per_cu_desc = per_cu;
     b.cus = cus;
     // experiment knobs (override svo_set_tuning)
     if (const char *e1 = getenv("SVO_PERSIST_WAVES_PER_CU")) b.waves_per_cu = atoi(e1);
     if (const char *e2 = getenv("SVO_PERSIST_THRESH")) b.thresh_num = atoi(e2);
   }
   {
-    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : b.max_per_cu;
+    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (desc ? b.max_per_cu_desc : b.max_per_cu);
     b.blocks = b.cus * per_cu;
   }
   const int spp = f.spp < 1 ? 1 : f.spp;
@@ -527,6 +616,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.thresh_num = b.thresh_num;
   a.fold = fold;
   a.group = kFoldGroup;
+  a.desc = desc; a.aux = aux; a.desc_count = desc_count;
   const long long work = (long long)f.ntiles * (f.batch > 1 ? f.batch : 1) * fold;
   const int blocks = work < (long long)b.blocks ? (int)work : b.blocks;
   // a ring of counter sets: frames may be in flight on different streams at the same time.  A frame's sample launches

@@ -1,0 +1,286 @@
+// svo_travloop2.h -- the traversal trips over the interior-descriptor table, in gfx950 assembly.
+//
+// trav_loop2() runs trav_step2() (svo_trav2.h) on the wave's active lanes until no more than `threshold` of them are
+// still traversing.  Against the byte walk's loop (svo_travloop.h) a trip loses: the child-offset arithmetic (two
+// shifts, a bit-op, an and, three popcounts, two mads: it is only needed for the hit pointer, once per cast, after the
+// loop), the two record loads of EVERY trip (the child's "empty" and "has a child block" bits come from the parent's
+// descriptor: one v_and + two v_cmp on a register), the cp / tag-mask extraction, and the 16-bit tag-mask plane of
+// the stack (a PUSH is one ds_write2_b32 of {descriptor offset, t_max}, a POP one ds_read2_b32).  What it gains is the
+// rank of the child among the parent's children with a child block (v_bfm, v_and, v_bcnt, v_lshl_add).
+//   trips load only for lanes that DESCEND or POP: one aligned 8-byte descriptor (49 cycles of the texture path per
+//   wave-level load against 2 x 34 for the two unaligned dwords of a record, tools/calib_td.hip), issued at the end
+//   of the trip for both lane sets together, waited for at the top of the next trip behind everything that does not
+//   need it (child slot, exit distances, the advance step).
+// Arithmetic, operand order and rounding are those of trav_step2() = trav_step() = svotrace.comp:262-369.
+//
+// Pinned registers: v[56:57] py,pz; v58 cell size (v[58:59] is the broadcast source of a packed multiply, v59 scratch);
+// v[60:61] tcy,tcz; v[62:63] temporaries; v[64:65] the parent's descriptor {first child descriptor, ne | has << 8}.
+#pragma once
+#include "svo_trav2.h"
+#include "svo_travloop.h"
+
+namespace svo {
+
+// SVO_DESC_LOAD_EARLY=1: the descending lanes' load leaves inside the descend section (more instructions between the
+// load and its use) and the popping lanes issue a second one; 0: one load per trip for both.
+#ifndef SVO_DESC_LOAD_EARLY
+#define SVO_DESC_LOAD_EARLY 0
+#endif
+#if SVO_DESC_LOAD_EARLY
+#define SVO_DESC_LOAD_D "buffer_load_dwordx2 v[64:65], %[self], %[rsd], 0 offen\n\t"
+#define SVO_DESC_LOAD_M                                                      \
+  "s_mov_b64 exec, %[sp]\n\t"                                                \
+  "buffer_load_dwordx2 v[64:65], %[self], %[rsd], 0 offen\n\t"
+#else
+#define SVO_DESC_LOAD_D
+#define SVO_DESC_LOAD_M                                                      \
+  "s_or_b64 exec, %[sd], %[sp]\n\t"                                          \
+  "buffer_load_dwordx2 v[64:65], %[self], %[rsd], 0 offen\n\t"
+#endif
+
+// per-ray constants and state in the register layout of trav_loop2()
+struct TravRegs2 {
+  float cx, bx;
+  f32x2 cyz, byz;
+  uint32_t octant;
+  float px;
+  f32x2 pyz;
+  float t_min, t_max, sexp, h;
+  int scale;
+  uint32_t cs;        // child slot of the last trip (index ^ octant): the slot a stopped lane stopped on
+  uint32_t self;      // byte offset of the parent state's descriptor
+  uint32_t dlo, dhi;  // that descriptor
+  uint32_t written, iter;
+  int lod_scale;
+};
+
+// set-up part of the cast (svotrace.comp:221-260); `rootd` = the root's descriptor, fetched once per wave
+__device__ __forceinline__ int trav_init_regs2(const uint2 rootd, TravRegs2 &t, V3 o, V3 d, const bool cone,
+                                               const float t_start = 0.0f) {
+  (void)cone;   // which lanes carry cone (secondary) rays is a lane set the caller passes to trav_loop2
+  t.iter = 0; t.cs = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
+  t.scale = kMaxScale - 1; t.sexp = 0.5f;
+  t.self = kDescRoot; t.dlo = rootd.x; t.dhi = rootd.y;
+  if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
+    t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0;
+    t.cx = t.cyz.x = t.cyz.y = t.bx = t.byz.x = t.byz.y = 0.0f; t.px = t.pyz.x = t.pyz.y = 1.0f;
+    return ST_CAPPED;
+  }
+  if (__builtin_fabsf(d.x) < kEpsilon) d.x = kEpsilon * sign_g(d.x);
+  if (__builtin_fabsf(d.y) < kEpsilon) d.y = kEpsilon * sign_g(d.y);
+  if (__builtin_fabsf(d.z) < kEpsilon) d.z = kEpsilon * sign_g(d.z);
+  t.cx = 1.0f / -__builtin_fabsf(d.x);
+  t.cyz.x = 1.0f / -__builtin_fabsf(d.y);
+  t.cyz.y = 1.0f / -__builtin_fabsf(d.z);
+  t.bx = t.cx * o.x; t.byz.x = t.cyz.x * o.y; t.byz.y = t.cyz.y * o.z;
+  t.octant = 0;
+  if (d.x > 0.0f) { t.octant ^= 1u; t.bx = 3.0f * t.cx - t.bx; }
+  if (d.y > 0.0f) { t.octant ^= 2u; t.byz.x = 3.0f * t.cyz.x - t.byz.x; }
+  if (d.z > 0.0f) { t.octant ^= 4u; t.byz.y = 3.0f * t.cyz.y - t.byz.y; }
+  t.t_min = vmax3(2.0f * t.cx - t.bx, 2.0f * t.cyz.x - t.byz.x, 2.0f * t.cyz.y - t.byz.y);
+  t.t_max = vmin3(t.cx - t.bx, t.cyz.x - t.byz.x, t.cyz.y - t.byz.y);
+  t.t_min = vmax(t.t_min, 0.0f);
+  t.t_min = vmax(t.t_min, t_start);   // beam pre-pass: the walk starts further along the same ray
+  t.h = t.t_max;
+  t.px = 1.0f; t.pyz.x = 1.0f; t.pyz.y = 1.0f;
+  if (1.5f * t.cx - t.bx > t.t_min) t.px = 1.5f;
+  if (1.5f * t.cyz.x - t.byz.x > t.t_min) t.pyz.x = 1.5f;
+  if (1.5f * t.cyz.y - t.byz.y > t.t_min) t.pyz.y = 1.5f;
+  return ST_ACTIVE;
+}
+
+__device__ __forceinline__ Cast trav_result_regs2(const BufPool &pool, const DescTab &tab, const TravRegs2 &t, int status) {
+  return cast_result2(pool, tab, status, t.self, t.cs, t.octant, t.iter, t.t_min, t.sexp, t.scale, t.px, t.pyz.x, t.pyz.y);
+}
+
+// Run trips until at most `threshold` lanes of `act` (the lanes with status == ST_ACTIVE) are still traversing.
+// Lanes that stop get their status (ST_HIT / ST_MISS / ST_CAPPED); r.self / r.cs then name the parent state and the
+// child slot they stopped on.  `cone_lanes`: the lanes whose ray is a cone (secondary) ray -- they drop to LOD 11 once
+// t_min > 0.05 (svotrace.comp:275-277).
+__device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, const uint32_t lane, TravRegs2 &r, int &status,
+                                           unsigned long long act, const int threshold, const unsigned long long cone_lanes,
+                                           uint32_t *mix = nullptr) {
+  const uint32_t lds8 = lds_offset(&stk.pm[lane]);
+  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp;
+  int cnt;
+#ifdef SVO_STAMPS
+#define SVO_RFL(i) (uint32_t) __builtin_amdgcn_readfirstlane((int)mix[i])
+  uint32_t c0 = SVO_RFL(0), c1 = SVO_RFL(1), c2 = SVO_RFL(2), c3 = SVO_RFL(3), c4 = SVO_RFL(4), c5 = SVO_RFL(5), c6 = SVO_RFL(6), c7 = SVO_RFL(7);
+#undef SVO_RFL
+#else
+  (void)mix;
+#endif
+  uint32_t t0, t1, t2, t3, bit;
+  float tcx, tcm;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n"
+      "Ltrip%=:\n\t"
+      "s_mov_b64 exec, %[act]\n\t"
+      SVO_COUNT("c0", "c1", "exec")
+      // ---- child slot (bit `scale` of the three position components), iteration cap (svotrace.comp:263-266)
+      "v_bfe_u32 %[t0], %[px], %[scale], 1\n\t"
+      "v_bfe_u32 %[t1], v56, %[scale], 1\n\t"
+      "v_bfe_u32 %[t2], v57, %[scale], 1\n\t"
+      "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"
+      "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n\t"                  // idx = x | y << 1 | z << 2
+      "v_xor_b32 %[cs], %[t0], %[oct]\n\t"                        // cs = idx ^ octant
+      "v_add_u32 %[iter], 1, %[iter]\n\t"                         // iter++
+      "v_cmp_lt_u32 vcc, 0x5dc, %[iter]\n\t"                      // iter > 1500
+      "v_lshlrev_b32_e64 %[bit], %[cs], %[k101]\n\t"              // bit cs of the ne byte and of the has byte
+      "s_mov_b64 %[sp], 0\n\t"
+      "s_cmp_lg_u64 vcc, 0\n\t"
+      "s_cbranch_scc1 Lcap%=\n"                                   // rare, out of line
+      "Lnocap%=:\n\t"
+      // ---- exit distances of the current cell (svotrace.comp:268-269)
+      "v_mul_f32 %[tcx], %[px], %[cx]\n\t"
+      "v_pk_mul_f32 v[60:61], v[56:57], %[cyz]\n\t"
+      "v_cmp_lt_f32 vcc, %[k005], %[tmin]\n\t"                    // t_min > 0.05 ...
+      "v_sub_f32 %[tcx], %[tcx], %[bx]\n\t"
+      "v_pk_add_f32 v[60:61], v[60:61], %[byz] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_and_b64 vcc, vcc, %[conem]\n\t"                          // ... on a cone (secondary) ray: LOD 11 from here on (sticky)
+      "v_cmp_le_f32_e64 %[sa], %[tmin], %[tmax]\n\t"              // t_min <= t_max
+      "v_min3_f32 %[tcm], %[tcx], v60, v61\n\t"                   // tc_max
+      "v_cndmask_b32_e64 %[lod], %[lod], 12, vcc\n\t"
+      "v_min_f32 %[t3], %[tmax], %[tcm]\n\t"                      // tv_max
+      "v_cmp_eq_u32_e64 %[sb], %[scale], %[lod]\n\t"              // at the LOD scale
+      "v_cmp_le_f32_e64 %[sc], %[tmin], %[t3]\n\t"                // t_min <= tv_max
+      "s_or_b64 %[se], %[sb], %[sc]\n\t"
+      "s_and_b64 %[se], %[se], %[sa]\n\t"                         // in range & (at LOD | inside): hits or descends if not empty
+      "s_andn2_b64 %[sd], %[sc], %[sb]\n\t"
+      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                         // in range & !at LOD & inside: descends if it has a child block
+      // the ADVANCE step of every active lane, while the descriptor of lanes that descended / popped is in flight
+      "v_cmp_le_f32 vcc, %[tcx], %[tcm]\n\t"
+      "v_cmp_le_f32_e64 %[sg], v60, %[tcm]\n\t"
+      "v_cmp_le_f32_e64 %[sh], v61, %[tcm]\n\t"
+      "v_cndmask_b32_e64 %[t0], 0, v58, vcc\n\t"                  // per-axis decrement: the cell size or 0
+      "v_cndmask_b32_e64 v62, 0, v58, %[sg]\n\t"
+      "v_cndmask_b32_e64 v63, 0, v58, %[sh]\n\t"
+      "v_cndmask_b32_e64 %[t2], 0, 1, %[sh]\n\t"
+      "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], %[sg]\n\t"
+      "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], vcc\n\t"     // step mask
+      "s_waitcnt vmcnt(0)\n\t"
+      "v_and_b32 %[bit], %[bit], v65\n\t"
+      "v_cmp_ne_u32_sdwa %[sa], %[bit], %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // child not empty
+      "v_cmp_ne_u32_sdwa vcc, %[bit], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"     // child has a child block
+      // lane sets
+      "s_and_b64 %[sd], %[sd], vcc\n\t"
+      "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = not empty & in range & !at LOD & inside & child block
+      "s_and_b64 %[se], %[se], %[sa]\n\t"                 // not empty & in range & (at LOD | inside)
+      "s_andn2_b64 %[sa], exec, %[se]\n\t"                // ADVANCE = the rest
+      "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = not empty & in range & (at LOD | (inside & no child block))
+      "s_mov_b64 exec, %[se]\n\t"
+      "v_mov_b32 %[st], 2\n\t"                            // ST_HIT
+      "s_andn2_b64 %[act], %[act], %[se]\n\t"
+      // ---- DESCEND (svotrace.comp:291-327)
+      "s_mov_b64 exec, %[sd]\n\t"
+      "s_cbranch_execz LnoD%=\n\t"
+      SVO_COUNT("c2", "c3", "exec")
+      "v_cmp_lt_f32 vcc, %[tcm], %[h]\n\t"                // tc_max < h: PUSH
+      "v_mul_f32 v58, 0.5, v58\n\t"                       // half
+      "v_add_u32 %[t1], -11, %[scale]\n\t"
+      "v_min_u32 %[t1], 11, %[t1]\n\t"                    // stack level
+      "s_and_saveexec_b64 %[sb], vcc\n\t"
+      "v_lshl_add_u32 v63, %[t1], 9, %[lds8]\n\t"
+      "ds_write2_b32 v63, %[self], %[tmax] offset1:1\n\t" // {parent state, t_max}
+      "v_lshl_or_b32 %[wr], 1, %[t1], %[wr]\n\t"
+      "s_mov_b64 exec, %[sd]\n\t"
+      "v_bfm_b32 %[t1], %[cs], 8\n\t"                     // the has bits of the children below cs
+      "v_and_b32 %[t1], %[t1], v65\n\t"
+      "v_bcnt_u32_b32 %[t1], %[t1], 0\n\t"
+      "v_lshl_add_u32 %[self], %[t1], 3, v64\n\t"         // the child's descriptor
+      SVO_DESC_LOAD_D
+      "v_mul_f32 %[t0], %[cx], v58\n\t"
+      "v_pk_mul_f32 v[62:63], %[cyz], v[58:59] op_sel_hi:[1,0]\n\t"
+      "v_add_f32 %[t0], %[t0], %[tcx]\n\t"                // centre distances
+      "v_pk_add_f32 v[62:63], v[62:63], v[60:61]\n\t"
+      "v_cmp_gt_f32 vcc, %[t0], %[tmin]\n\t"
+      "v_cmp_gt_f32_e64 %[sb], v62, %[tmin]\n\t"
+      "v_cmp_gt_f32_e64 %[sc], v63, %[tmin]\n\t"
+      "v_add_u32 %[scale], -1, %[scale]\n\t"
+      "v_mov_b32 %[h], %[tcm]\n\t"                        // h = tc_max
+      "v_cndmask_b32_e64 %[t0], 0, v58, vcc\n\t"
+      "v_cndmask_b32_e64 v62, 0, v58, %[sb]\n\t"
+      "v_cndmask_b32_e64 v63, 0, v58, %[sc]\n\t"
+      "v_add_f32 %[px], %[px], %[t0]\n\t"
+      "v_pk_add_f32 v[56:57], v[56:57], v[62:63]\n\t"
+      "v_mov_b32 %[tmax], %[t3]\n"                        // t_max = tv_max
+      "LnoD%=:\n\t"
+      // ---- ADVANCE (svotrace.comp:329-339)
+      "s_mov_b64 exec, %[sa]\n\t"
+      "s_cbranch_execz LnoA%=\n\t"
+      SVO_COUNT("c4", "c5", "exec")
+      "v_mov_b32 %[tmin], %[tcm]\n\t"                     // t_min = tc_max
+      "v_sub_f32 %[px], %[px], %[t0]\n\t"
+      "v_pk_add_f32 v[56:57], v[56:57], v[62:63] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_bitop3_b32 %[t2], %[t2], %[cs], %[oct] bitop3:0x90\n\t"   // step & ~idx (idx = cs ^ octant): an axis stepped out of the lower half
+      "v_cmp_ne_u32 vcc, 0, %[t2]\n\t"                    // left the parent: POP
+      "s_mov_b64 %[sp], vcc\n\t"
+      "s_mov_b64 exec, vcc\n\t"
+      "s_cbranch_execz LnoA%=\n\t"
+      SVO_COUNT("c6", "c7", "exec")
+      // ---- POP (svotrace.comp:341-366)
+      "v_add_f32 %[t0], %[px], %[t0]\n\t"                 // position before the step (exact)
+      "v_pk_add_f32 v[62:63], v[56:57], v[62:63]\n\t"
+      "v_xor_b32 %[t0], %[t0], %[px]\n\t"
+      "v_xor_b32 %[t1], v62, v56\n\t"
+      "v_bitop3_b32 %[t0], %[t0], v63, v57 bitop3:0xf6\n\t"   // a | (b ^ c)
+      "v_or3_b32 %[t0], %[t0], %[t1], 1\n\t"              // differing bits (| 1 keeps ffbh defined)
+      "v_ffbh_u32 %[t0], %[t0]\n\t"
+      "v_sub_u32 %[t2], 20, %[t0]\n\t"                    // scale - 11
+      "v_xor_b32 %[scale], 31, %[t0]\n\t"                 // scale = 31 - leading zeros
+      "v_min_u32 %[t1], 11, %[t2]\n\t"
+      "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"     // cell size = 2^(scale - 23)
+      "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
+      "ds_read2_b32 v[62:63], %[t0] offset1:1\n\t"
+      "v_bfe_i32 %[t2], %[wr], %[t2], 1\n\t"              // all ones if this ray pushed that level
+      "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
+      "v_mov_b32 %[h], 0\n\t"                             // h = 0
+      "v_and_b32 %[px], %[px], %[t3]\n\t"                 // round the position to the cell
+      "v_and_b32 v56, v56, %[t3]\n\t"
+      "v_and_b32 v57, v57, %[t3]\n\t"
+      "v_cmp_le_u32 vcc, 23, %[scale]\n\t"                // left the octree: MISS
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_and_b32 %[self], %[t2], v62\n\t"                 // never pushed: state (0, 0) = descriptor 0, t_max 0
+      "v_and_b32 %[tmax], %[t2], v63\n\t"
+      "s_cmp_lg_u64 vcc, 0\n\t"
+      "s_cbranch_scc1 Lmiss%=\n"                          // out of line
+      "LnoA%=:\n\t"
+      // ---- the descriptors of the lanes that changed their parent state
+      SVO_DESC_LOAD_M
+      "s_bcnt1_i32_b64 %[cnt], %[act]\n\t"
+      "s_cmp_gt_i32 %[cnt], %[thresh]\n\t"
+      "s_cbranch_scc1 Ltrip%=\n\t"
+      "s_branch Lend%=\n"
+      "Lcap%=:\n\t"                                       // iteration cap: status = ST_CAPPED, lane out of the loop
+      "s_mov_b64 exec, vcc\n\t"
+      "v_mov_b32 %[st], 4\n\t"
+      "s_andn2_b64 %[act], %[act], vcc\n\t"
+      "s_mov_b64 exec, %[act]\n\t"
+      "s_branch Lnocap%=\n"
+      "Lmiss%=:\n\t"                                      // left the octree: status = ST_MISS
+      "s_mov_b64 exec, vcc\n\t"
+      "v_mov_b32 %[st], 3\n\t"
+      "s_andn2_b64 %[act], %[act], vcc\n\t"
+      "s_andn2_b64 %[sp], %[sp], vcc\n\t"
+      "s_branch LnoA%=\n"
+      "Lend%=:\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      : [px] "+v"(r.px), "+{v[56:57]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v58}"(r.sexp), [h] "+v"(r.h),
+        [scale] "+v"(r.scale), [cs] "+v"(r.cs), [self] "+v"(r.self), "+{v64}"(r.dlo), "+{v65}"(r.dhi), [wr] "+v"(r.written),
+        [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
+        [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
+        [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
+        [sp] "=&s"(sp), [cnt] "=&s"(cnt)
+#ifdef SVO_STAMPS
+        , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
+#endif
+      : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
+        [lds8] "v"(lds8), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
+      : "vcc", "scc", "memory", "v59", "v60", "v61", "v62", "v63");
+#ifdef SVO_STAMPS
+  mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7;
+#endif
+}
+
+}  // namespace svo

@@ -17,7 +17,7 @@ EXPORTS = [
     "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_build_from_voxels", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_set_batch", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel", "svo_read_beam",
-    "svo_output_device_ptrs",
+    "svo_output_device_ptrs", "svo_set_derived", "svo_derived_info",
 ]
 
 
@@ -72,6 +72,8 @@ def lib(path=None):
         L.svo_set_progressive.argtypes = [vp, ci]
         L.svo_set_batch.argtypes = [vp, ci, u64]
         L.svo_set_tuning.argtypes = [vp, ci, ci]
+        L.svo_set_derived.argtypes = [vp, ci]
+        L.svo_derived_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ci), fp]
         L.svo_dispatch.argtypes = [vp]
         L.svo_dispatch_async.argtypes = [vp]
         L.svo_sync.argtypes = [vp]
@@ -198,6 +200,16 @@ class HipContext:
 
     def set_tuning(self, waves_per_cu=0, round_threshold_sixteenths=0):
         self._chk(self._L.svo_set_tuning(self._h, int(waves_per_cu), int(round_threshold_sixteenths)))
+
+    def set_derived(self, mode):
+        """0 = walk the pool's records as the shader does, 1 (default) = walk the interior-descriptor table when the
+        pool is derivable."""
+        self._chk(self._L.svo_set_derived(self._h, int(mode)))
+
+    def derived_info(self):
+        n, b, w, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int(), ctypes.c_float()
+        self._chk(self._L.svo_derived_info(self._h, ctypes.byref(n), ctypes.byref(b), ctypes.byref(w), ctypes.byref(ms)))
+        return {"descriptors": int(n.value), "bytes": int(b.value), "walkable": bool(w.value), "build_ms": float(ms.value)}
 
     def set_batch(self, nframes, frame_stride=0):
         self._chk(self._L.svo_set_batch(self._h, int(nframes), int(frame_stride)))

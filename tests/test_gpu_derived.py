@@ -1,0 +1,148 @@
+"""The interior-descriptor table (svo-raytracer_amd/csrc/svo_derive.hip.h) against the reference shader's goldens.
+
+Pipeline 1 walks the table when the pool is derivable and the pool's records otherwise; every other GPU test runs it
+in its default mode (table when possible).  Here: both modes on every golden pool -- the llvmpipe goldens, and the 397
+fuzz / mangled cases (pools with overlapping, backward and out-of-range child pointers) -- bit for bit, which of them
+are walkable, that builder-made pools always are, and that the table follows ranged pool updates."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import compare_with_golden, golden_case, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from svo_raytracer_amd import hiplib
+    c = hiplib.HipContext(0)
+    c.set_pipeline(1)
+    yield c
+    c.set_derived(1)
+    c.close()
+
+
+def _same(a, b):
+    bad = {"rgba": int((a["rgba"] != b["rgba"]).any(axis=2).sum()),
+           "depth": int((a["depth"].view(np.uint32) != b["depth"].view(np.uint32)).sum())}
+    for k in ("pointer", "value", "raw_normal", "level", "iter"):
+        bad[k] = int((a["hits"][k] != b["hits"][k]).sum())
+    bad["t"] = int((a["hits"]["t"].view(np.uint32) != b["hits"]["t"].view(np.uint32)).sum())
+    return bad
+
+
+@pytest.mark.parametrize("derived", [1, 0])
+@pytest.mark.parametrize("name,poolkey", golden_cases())
+def test_both_walks_match_reference_shader_golden(ctx, name, poolkey, derived):
+    g = golden_case(name, poolkey)
+    ctx.set_derived(derived)
+    res = ctx.render(g["pool"], g["w"], g["h"], g["cam"], g["frame"], g["mode"])
+    bad = compare_with_golden(res, g)
+    assert bad == {k: 0 for k in bad}, bad
+
+
+def test_builder_made_golden_pools_are_walkable(ctx):
+    """Every pool of the llvmpipe fixture that a builder made (terrains, embeddings, dust, brush-edited) must take the
+    table path; the report says how many descriptors each needs."""
+    from helpers import golden
+    z = golden()
+    ctx.set_derived(1)
+    seen = {}
+    for name, poolkey in golden_cases():
+        if poolkey in seen:
+            continue
+        pool = z["pool/" + poolkey]
+        ctx.pool_upload(pool)
+        seen[poolkey] = (pool.size, ctx.derived_info())
+    print({k: (n, i["descriptors"], i["walkable"]) for k, (n, i) in seen.items()})
+    assert all(i["walkable"] for _, i in seen.values()), {k: i for k, (n, i) in seen.items() if not i["walkable"]}
+    # a proper tree has at most one state per 15 bytes of pool (an interior record + the smallest child block); the
+    # phantom state's children that are not records of the tree unroll into a few more
+    assert all(i["descriptors"] <= n // 8 + 4096 for n, i in seen.values())
+
+
+def _fuzz():
+    return np.load(os.path.join(HERE, "golden", "fuzz_golden.npz"))
+
+
+def _fuzz_cases():
+    return [tuple(s.split(":")) for s in _fuzz()["index"]]
+
+
+@pytest.mark.parametrize("poolkey", sorted({pk for _, pk in _fuzz_cases()}))
+def test_both_walks_match_reference_shader_on_fuzz_pools(ctx, poolkey):
+    z = _fuzz()
+    pool = z["pool/" + poolkey]
+    names = [n for n, pk in _fuzz_cases() if pk == poolkey]
+    for derived in (1, 0):
+        ctx.set_derived(derived)
+        for i, name in enumerate(names):
+            w, h, frame, mode, same = (int(v) for v in z[name + "/meta"])
+            path = z[name + "/path"] if name + "/path" in z.files else (2, 0)
+            g = dict(rgba=z[name + "/rgba"], depth_bits=z[name + "/depth_bits"], first_hit=z[name + "/first_hit"])
+            res = ctx.render(pool if i == 0 else None, w, h, z[name + "/cam"], frame, mode, bounces=int(path[0]),
+                             mirror_mask=int(path[1]))
+            bad = compare_with_golden(res, g)
+            assert bad == {k: 0 for k in bad}, (name, derived, bad)
+
+
+def test_fuzz_pools_walkability_report(ctx):
+    """Which of the fuzz fixture's pools the table can state (the others fall back to the records): the scene and tiny
+    pools must be among them; mangled ones may or may not."""
+    z = _fuzz()
+    ctx.set_derived(1)
+    out = {}
+    for pk in sorted({pk for _, pk in _fuzz_cases()}):
+        ctx.pool_upload(z["pool/" + pk])
+        out[pk] = ctx.derived_info()
+    walk = sorted(k for k, i in out.items() if i["walkable"])
+    print("walkable:", len(walk), "of", len(out), "| not:", sorted(k for k in out if k not in walk))
+    assert all(out[k]["walkable"] for k in out if k[0] in "st"), [k for k in out if k[0] in "st" and not out[k]["walkable"]]
+    assert len(walk) >= len(out) // 2
+
+
+@pytest.mark.parametrize("n,cam,mode", [(256, "K1", 0), (512, "K0", 2), (1024, "K2", 0)])
+def test_table_walk_equals_record_walk_and_oracle(ctx, n, cam, mode):
+    import svo_raytracer_amd.scene as scene
+    from oracle import oracle
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(n)
+    ctx.set_derived(1)
+    a = ctx.render(pool, 320, 200, CAMERAS[cam], 3, mode)
+    info = ctx.derived_info()
+    assert info["walkable"] and 2 < info["descriptors"] <= pool.size // 15 + 4096
+    ctx.set_derived(0)
+    b = ctx.render(None, 320, 200, CAMERAS[cam], 3, mode)
+    assert _same(a, b) == {k: 0 for k in _same(a, b)}
+    ref = oracle.render(pool, 320, 200, CAMERAS[cam], 3, mode)
+    bad = _same(a, ref)
+    assert bad == {k: 0 for k in bad}, bad
+
+
+def test_table_follows_ranged_pool_updates(ctx):
+    """svo_pool_update changes records in place and appends new ones (Octree.useSDFBrush -> Renderer.updateSSBO,
+    Main.java:349-350): the next dispatch must walk the edited tree."""
+    import svo_raytracer_amd.scene as scene
+    from oracle import oracle
+    from svo_raytracer_amd.cameras import CAMERAS
+    a, _ = scene.build_scene(128)
+    b, _ = scene.build_scene(256)   # a different tree: stands in for an arbitrary edit, uploaded range by range
+    ctx.set_derived(1)
+    ctx.render(a, 160, 96, CAMERAS["K1"], 2, 0)
+    d0 = ctx.derived_info()["descriptors"]
+    big = np.zeros(max(a.size, b.size), np.uint8)
+    big[:b.size] = b
+    third = b.size // 3
+    for s, e in ((0, third), (third, 2 * third), (2 * third, b.size)):
+        ctx.pool_update(big, s, e)
+    if a.size > b.size:
+        ctx.pool_update(big, b.size, a.size)   # zero what is left of the old pool
+    res = ctx.render(None, 160, 96, CAMERAS["K1"], 2, 0)
+    assert ctx.derived_info()["descriptors"] != d0
+    ref = oracle.render(b, 160, 96, CAMERAS["K1"], 2, 0)
+    bad = _same(res, ref)
+    assert bad == {k: 0 for k in bad}, bad
