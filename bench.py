@@ -99,6 +99,8 @@ def parse(argv=None):
     ap.add_argument("--isolated", type=int, default=1, help="also time single frames with the GPU to themselves (kernel_ms_isolated); "
                                                           "0 in PMC passes, so that every launch of the kernel is a timed-region launch")
     ap.add_argument("--beam", type=int, default=0, help="useBeamOptimization (coarse depth pre-pass, Main.java:257-266)")
+    ap.add_argument("--comm-cus", type=int, default=-1, help="CUs per XCD the render streams leave free for the collective's kernels "
+                                                              "(svo_set_reserved_cus); -1 = 1 when ranks exchange tiles, else 0")
     ap.add_argument("--as-rank", default=None, help="r/n: render what rank r of n would, on one GPU, no communication")
     args = ap.parse_args(argv)
     preset = PRESETS[args.config or "C3"]
@@ -268,6 +270,8 @@ def main():
         ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and
                                             # frame, rounds once 7/16 of the traversing lanes have stopped (tools/history/sweep*.sh)
     ctx.set_hit_records(bool(args.hits))
+    comm_cus = args.comm_cus if args.comm_cus >= 0 else (1 if use_comm else 0)
+    ctx.set_reserved_cus(comm_cus)
     params = dict(render_mode=args.mode, buffer_end=nbytes, use_beam=args.beam, bounces=args.bounces,
                   mirror_mask=args.mirror, spp=args.spp)
     ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device="cuda",
@@ -275,10 +279,7 @@ def main():
                      first_frame=2, params=params, as_rank=as_rank, batch=batch)
 
     # ---- ray count (untimed counting pass of the first and the last timed frame) ---------------------
-    def count(frame):
-        c, d, h = ring._ptrs(0)
-        ctx.set_stream(ring.streams[0].cuda_stream)
-        ctx.bind_outputs(c, d, h)
+    def count(frame):    # on the context's own stream and images (the ring's slots are not involved)
         ctx.set_batch(1, 0)
         ctx.set_params(frame, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
         return ctx.count_frame()
@@ -349,11 +350,12 @@ def main():
                 "(%d pixels): rgba8 + depth bits vs the CPU oracle, %d mismatches" % (frames, nbuf, batch, step, npx, bad)
 
     # ---- kernel time by HIP events on the dispatch streams; then one frame at a time with the GPU to itself ----
-    kernel_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ring.launch_events]))  # with nbuf launches in flight
+    # (svo_ring_query: events around every submission on its slot's stream; whole batches only, so that every launch
+    # averaged carries the same number of frames)
+    full = [m for m, n in ring.launch_ms if m > 0 and n == batch] or [m for m, n in ring.launch_ms if m > 0]
+    kernel_ms = float(np.mean(full)) if full else 0.0   # with nbuf launches in flight
     if args.pipeline == 1:
         ctx.set_tuning(0, args.thresh)   # one frame at a time: fill the GPU
-    c0, d0, h0 = ring._ptrs(0)
-    ctx.bind_outputs(c0, d0, h0)
     ctx.set_batch(1, 0)
     ctx.set_params(first_timed, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
     kernel_ms_isolated = float(np.mean(ctx.time_frames(2, max(5, min(args.steps, 30))))) if args.isolated else None

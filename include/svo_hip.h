@@ -193,10 +193,46 @@ int svo_get_stats(svo_ctx *ctx, svo_stats *out);
  * The library rotates its per-frame work counters / queues / accumulators / beam images over small rings and
  * orders their re-use with events, so any number of dispatches may be outstanding (more than 8 serialise).
  * HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): two frame streams on one queue serialise. */
-int svo_set_stream(svo_ctx *ctx, void *hip_stream);
+int svo_set_stream(svo_ctx *ctx, void *hip_stream);   /* NULL: back to the library's own stream (kept for the context's lifetime) */
 /* time `iters` back-to-back frames with HIP events on the dispatch stream after `warmup`
  * untimed ones; per-frame milliseconds into ms[iters] */
 int svo_time_frames(svo_ctx *ctx, int warmup, int iters, float *ms);
+
+/* ---- frames in flight behind the boundary --------------------------------------------- */
+/* The reference's loop renders one frame and reads the crosshair back (Main.java:132-146, 257-289): svo_dispatch +
+ * svo_read_pixel.  The throughput mode bench.py times -- several launches in flight, several consecutive frames of the
+ * camera per launch, so that a launch's tail (its longest paths) overlaps the next launch -- needs streams and output
+ * buffers a host like Java cannot own.  The ring owns them: `slots` output sets (colour, depth [, hit records]) of
+ * `frames_per_slot` frames each, every slot with a HIP stream of its own.  svo_resize (a new image size) destroys the
+ * ring; pool changes wait for every frame in flight as always.  The process should run with GPU_MAX_HW_QUEUES >= slots
+ * (svo_create sets 8 when it makes the process's first HIP call and the variable is unset). */
+int svo_ring_create(svo_ctx *ctx, int slots, int frames_per_slot, int want_hits);
+/* Persistent waves hold their CU slots for a whole launch; a collective's kernels (RCCL send / receive of the tile
+ * gather) queued next to four such launches only start when a launch drains.  per_xcd > 0 makes the NEXT
+ * svo_ring_create build its streams with a CU mask that leaves that many CUs of each of the 8 XCDs free
+ * (hipExtStreamCreateWithCUMask), so that a collective on another stream always finds room; 0 (default) = all CUs. */
+int svo_set_reserved_cus(svo_ctx *ctx, int per_xcd);
+int svo_ring_destroy(svo_ctx *ctx);
+/* enqueue frames frame_number .. frame_number + nframes - 1 (what nframes turns of Main.updateEarly with a static
+ * camera render, Main.java:275) with the context's current camera / params / stripes / tuning into the next slot
+ * (round robin; a slot's re-use is ordered behind its previous frames by its stream); returns at once. */
+int svo_ring_submit(svo_ctx *ctx, int frame_number, int nframes, int *slot);
+/* host waits until the slot's last submission is complete */
+int svo_ring_wait(svo_ctx *ctx, int slot);
+/* non-blocking: *done = 1 when complete; the first frameNumber and the number of frames it holds; GPU milliseconds
+ * between the start and the end of its launches (HIP events on the slot's stream; 0 while running).  Any may be NULL. */
+int svo_ring_query(svo_ctx *ctx, int slot, int *done, int *first_frame, int *nframes, float *gpu_ms);
+/* readback of frame k of a slot (waits for the slot): glGetTexImage of images 0 / 1 (Main.java:132-146) */
+int svo_ring_read_color(svo_ctx *ctx, int slot, int k, void *rgba8);
+int svo_ring_read_depth(svo_ctx *ctx, int slot, int k, float *depth);
+int svo_ring_read_hits(svo_ctx *ctx, int slot, int k, svo_hit *hits);
+int svo_ring_read_pixel(svo_ctx *ctx, int slot, int k, int x, int y, void *rgba8, float *depth, svo_hit *hit);
+/* multi-GPU: a slot may render into caller-owned device buffers instead (a rank's chunk of an RCCL gather buffer):
+ * frame k at element offset k * frame_stride of each; color == NULL returns the slot to its own images */
+int svo_ring_bind_slot(svo_ctx *ctx, int slot, void *color, void *depth, void *hits, uint64_t frame_stride);
+/* device pointers of a slot's images, their frame stride in elements, and the slot's hipStream_t (to order a
+ * collective that reads the slot behind its frames).  Any may be NULL. */
+int svo_ring_device_ptrs(svo_ctx *ctx, int slot, void **color, void **depth, void **hits, uint64_t *frame_stride, void **stream);
 
 /* ---- readback ------------------------------------------------------------------- */
 /* replaces glGetTexImage of image 0 (rgba8; row 0 = p.y = 0, bytes R,G,B,A) and

@@ -67,6 +67,40 @@ jint Java_src_engine_HipRenderer_nBindOutputs(void *env, void *cls, jlong ctx, j
 /* the commented-out cross-frame accumulation of svotrace.comp:712-719 */
 jint Java_src_engine_HipRenderer_nSetProgressive(void *env, void *cls, jlong ctx, jint enabled);
 
+
+/* ---- the rest of the C ABI's dispatch surface (include/svo_hip.h), same LWJGL style ---- */
+jint Java_src_engine_HipRenderer_nDispatchAsync(void *env, void *cls, jlong ctx);
+jint Java_src_engine_HipRenderer_nSync(void *env, void *cls, jlong ctx);
+/* hipStream_t as a long; 0 = the library's own stream */
+jint Java_src_engine_HipRenderer_nSetStream(void *env, void *cls, jlong ctx, jlong hip_stream);
+jint Java_src_engine_HipRenderer_nSetPipeline(void *env, void *cls, jlong ctx, jint pipeline);
+jint Java_src_engine_HipRenderer_nSetTuning(void *env, void *cls, jlong ctx, jint waves_per_cu, jint round_threshold_sixteenths);
+jint Java_src_engine_HipRenderer_nSetDerived(void *env, void *cls, jlong ctx, jint mode);
+jint Java_src_engine_HipRenderer_nSetHitRecords(void *env, void *cls, jlong ctx, jint enabled);
+jint Java_src_engine_HipRenderer_nSetRows(void *env, void *cls, jlong ctx, jint y0, jint y1);
+jint Java_src_engine_HipRenderer_nSetStripes(void *env, void *cls, jlong ctx, jint first_tile_row, jint tile_row_step,
+                                             jint n_tile_rows, jint out_row0);
+/* svo_count_frame / svo_get_stats: address of a 64-byte svo_stats (six u64, f32 last_dispatch_ms, i32 device) */
+jint Java_src_engine_HipRenderer_nCountFrame(void *env, void *cls, jlong ctx, jlong stats_addr);
+jint Java_src_engine_HipRenderer_nGetStats(void *env, void *cls, jlong ctx, jlong stats_addr);
+/* svo_derived_info: descriptors of the table, or a negative status; *walkable_addr (4 bytes, may be 0) = 1 if walked */
+jlong Java_src_engine_HipRenderer_nDerivedInfo(void *env, void *cls, jlong ctx, jlong walkable_addr);
+/* ---- frames in flight (svo_ring_*): what a Java host cannot own -- streams, device buffers -- stays in the library */
+jint Java_src_engine_HipRenderer_nRingCreate(void *env, void *cls, jlong ctx, jint slots, jint frames_per_slot, jint want_hits);
+jint Java_src_engine_HipRenderer_nRingDestroy(void *env, void *cls, jlong ctx);
+/* returns the slot (>= 0) the frames went to, or a negative status */
+jint Java_src_engine_HipRenderer_nRingSubmit(void *env, void *cls, jlong ctx, jint frame_number, jint nframes);
+jint Java_src_engine_HipRenderer_nRingWait(void *env, void *cls, jlong ctx, jint slot);
+/* 1 = complete, 0 = still running, negative = status; *ms_addr (4 bytes, may be 0) = GPU milliseconds of the slot */
+jint Java_src_engine_HipRenderer_nRingDone(void *env, void *cls, jlong ctx, jint slot, jlong ms_addr);
+jint Java_src_engine_HipRenderer_nRingReadColor(void *env, void *cls, jlong ctx, jint slot, jint k, jlong addr);
+jint Java_src_engine_HipRenderer_nRingReadDepth(void *env, void *cls, jlong ctx, jint slot, jint k, jlong addr);
+jint Java_src_engine_HipRenderer_nRingReadHits(void *env, void *cls, jlong ctx, jint slot, jint k, jlong addr);
+jint Java_src_engine_HipRenderer_nRingReadPixel(void *env, void *cls, jlong ctx, jint slot, jint k, jint x, jint y,
+                                                jlong rgba_addr, jlong depth_addr, jlong hit_addr);
+jint Java_src_engine_HipRenderer_nRingBindSlot(void *env, void *cls, jlong ctx, jint slot, jlong color_dptr, jlong depth_dptr,
+                                               jlong hits_dptr, jlong frame_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,6 +193,79 @@ public class HipRenderer {
     this.spp = spp;
   }
 
+  // ---- frames in flight (svo_ring_*): the throughput mode bench.py times, from Java ---------------------------
+  // Main.updateEarly renders a frame and reads the crosshair back before the next one (Main.java:132-146, 257-289).
+  // A host that does not need every frame's result at once (offline renders, progressive GI with a static camera,
+  // several viewports) can keep `slots` launches of `framesPerSlot` consecutive frames in flight instead: the
+  // library owns the streams and the device images.
+
+  /** Create (or re-create) the ring; call after the first dispatchCompute / setImageSize has fixed the image size. */
+  public void createFrameRing(int slots, int framesPerSlot, boolean wantHits) {
+    check(nResize(ctx, width, height));
+    check(nRingCreate(ctx, slots, framesPerSlot, wantHits ? 1 : 0));
+  }
+
+  public void destroyFrameRing() {
+    check(nRingDestroy(ctx));
+  }
+
+  /**
+   * Enqueue frames firstFrameNumber .. firstFrameNumber + nframes - 1 of the current camera (what nframes turns of
+   * Main.updateEarly with a static camera render: Main.java:275 only increments frameNumber).  Returns the slot the
+   * frames went to (pass it to awaitFrames / readFrame), or a negative status.  Does not wait.
+   */
+  public int submitFrames(int firstFrameNumber, int nframes) {
+    check(nSetParams(ctx, firstFrameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+    int slot = nRingSubmit(ctx, firstFrameNumber, nframes);
+    if (slot < 0)
+      printGLErrors();
+    else
+      frameNumber = firstFrameNumber + nframes - 1;
+    return slot;
+  }
+
+  /** Block until the frames of a slot are complete. */
+  public void awaitFrames(int slot) {
+    check(nRingWait(ctx, slot));
+  }
+
+  /** Non-blocking: true once the slot's frames are complete. */
+  public boolean framesDone(int slot) {
+    return nRingDone(ctx, slot, 0L) == 1;
+  }
+
+  /** glGetTexImage of image 0 / image 1 for frame k of a slot (waits for the slot). */
+  public void readFrame(int slot, int k, ByteBuffer rgba8, ByteBuffer depth) {
+    if (rgba8 != null)
+      check(nRingReadColor(ctx, slot, k, MemoryUtil.memAddress(rgba8)));
+    if (depth != null)
+      check(nRingReadDepth(ctx, slot, k, MemoryUtil.memAddress(depth)));
+  }
+
+  /** The crosshair pick of Main.java:132-146 on frame k of a slot. */
+  public float readFrameDepthPixel(int slot, int k, int x, int y) {
+    ByteBuffer one = MemoryUtil.memAlloc(4);
+    check(nRingReadPixel(ctx, slot, k, x, y, 0L, MemoryUtil.memAddress(one), 0L));
+    float d = one.getFloat(0);
+    MemoryUtil.memFree(one);
+    return d;
+  }
+
+  /** Launch shape of the persistent pipeline: about 10 waves per CU with several launches in flight, 0 = fill the GPU. */
+  public void setTuning(int wavesPerCu, int roundThresholdSixteenths) {
+    check(nSetTuning(ctx, wavesPerCu, roundThresholdSixteenths));
+  }
+
+  /** 0 one thread per pixel (the shader's decomposition), 1 persistent waves (fastest), 2 staged wavefront. */
+  public void setPipeline(int pipeline) {
+    check(nSetPipeline(ctx, pipeline));
+  }
+
+  /** Multi-GPU split by interleaved 8-pixel tile rows (one HipRenderer context per GPU). */
+  public void setStripes(int firstTileRow, int tileRowStep, int nTileRows, int outRow0) {
+    check(nSetStripes(ctx, firstTileRow, tileRowStep, nTileRows, outRow0));
+  }
+
   private void check(int rc) {
     if (rc != 0)
       printGLErrors();
@@ -220,4 +293,27 @@ public class HipRenderer {
   private static native int nReadBeam(long ctx, long addr);
   private static native long nBuildFromHeightmap(long ctx, long heightAddr, long materialAddr, int n);
   private static native int nReadPixel(long ctx, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);
+  private static native int nDispatchAsync(long ctx);
+  private static native int nSync(long ctx);
+  private static native int nSetStream(long ctx, long hipStream);
+  private static native int nSetPipeline(long ctx, int pipeline);
+  private static native int nSetTuning(long ctx, int wavesPerCu, int roundThresholdSixteenths);
+  private static native int nSetDerived(long ctx, int mode);
+  private static native int nSetHitRecords(long ctx, int enabled);
+  private static native int nSetRows(long ctx, int y0, int y1);
+  private static native int nSetStripes(long ctx, int firstTileRow, int tileRowStep, int nTileRows, int outRow0);
+  private static native int nCountFrame(long ctx, long statsAddr);
+  private static native int nGetStats(long ctx, long statsAddr);
+  private static native long nDerivedInfo(long ctx, long walkableAddr);
+  private static native int nRingCreate(long ctx, int slots, int framesPerSlot, int wantHits);
+  private static native int nRingDestroy(long ctx);
+  private static native int nRingSubmit(long ctx, int frameNumber, int nframes);
+  private static native int nRingWait(long ctx, int slot);
+  private static native int nRingDone(long ctx, int slot, long msAddr);
+  private static native int nRingReadColor(long ctx, int slot, int k, long addr);
+  private static native int nRingReadDepth(long ctx, int slot, int k, long addr);
+  private static native int nRingReadHits(long ctx, int slot, int k, long addr);
+  private static native int nRingReadPixel(long ctx, int slot, int k, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);
+  private static native int nRingBindSlot(long ctx, int slot, long colorDevicePtr, long depthDevicePtr, long hitsDevicePtr,
+      long frameStride);
 }

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,8 +24,8 @@ static_assert(sizeof(svo_hit) == 16, "svo_hit must be 16 bytes");
 
 struct svo_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = true;
+  hipStream_t stream = nullptr;       // the stream dispatches go to: own_stream, or the caller's (svo_set_stream)
+  hipStream_t own_stream = nullptr;   // created with the context, kept for its lifetime
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // pool
   uint8_t *d_pool = nullptr;
@@ -66,6 +67,21 @@ struct svo_ctx {
   int derived_mode = 1;           // 0 = always walk the records, 1 = walk the table when there is one
   WavefrontBuffers wf;
   PersistBuffers pb;
+  // frames in flight behind the boundary (svo_ring_*): per slot a stream of its own, output buffers for up to
+  // ring_frames consecutive frames, and the events around its last submission
+  struct RingSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint32_t *color = nullptr; float *depth = nullptr; uint4 *hits = nullptr;      // library-owned
+    void *xcolor = nullptr, *xdepth = nullptr, *xhits = nullptr; uint64_t xstride = 0;   // caller-owned (svo_ring_bind_slot)
+    int first_frame = 0, nframes = 0;
+    bool used = false;
+  };
+  std::vector<RingSlot> ring;
+  int reserved_cus = 0;        // CUs per XCD the ring's streams leave free (svo_set_reserved_cus)
+  int ring_frames = 0;
+  uint64_t ring_stride = 0;    // elements between consecutive frames of a library-owned slot
+  unsigned ring_next = 0;
   svo_stats stats{};
   std::string err;
 };
@@ -88,22 +104,42 @@ extern "C" {
 int svo_create(int device, svo_ctx **out) {
   if (!out) return SVO_E_INVALID;
   *out = nullptr;
+  // Frames in flight (svo_ring_*) want a hardware queue per stream; HIP maps streams onto GPU_MAX_HW_QUEUES queues
+  // (default 4: two frame streams on one queue serialise their launches).  Read when the runtime starts, so this only
+  // has an effect when the library makes the process's first HIP call (a JVM host); it never overrides the caller's value.
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SVO_E_NODEVICE;
   svo_ctx *c = new svo_ctx();
   c->device = device;
   c->stats.device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipMalloc((void **)&c->d_counters, sizeof(DeviceCounters)) != hipSuccess) {
     delete c;
     return SVO_E_HIP;
   }
+  c->stream = c->own_stream;
   *out = c;
   return SVO_OK;
 }
 
+static void ring_free(svo_ctx *c) {
+  for (auto &s : c->ring) {
+    if (s.color) (void)hipFree(s.color);
+    if (s.depth) (void)hipFree(s.depth);
+    if (s.hits) (void)hipFree(s.hits);
+    if (s.e0) (void)hipEventDestroy(s.e0);
+    if (s.e1) (void)hipEventDestroy(s.e1);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  c->ring.clear();
+  c->pb.cus_reserved = 0;
+  c->ring_frames = 0; c->ring_stride = 0; c->ring_next = 0;
+}
+
 static void free_outputs(svo_ctx *c) {
+  ring_free(c);   // the ring's images have the size of the frame
   if (c->own_color) (void)hipFree(c->own_color);
   if (c->own_depth) (void)hipFree(c->own_depth);
   if (c->own_hits) (void)hipFree(c->own_hits);
@@ -131,7 +167,8 @@ int svo_destroy(svo_ctx *c) {
   derive::free_table(c->dt);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  ring_free(c);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return SVO_OK;
 }
@@ -146,10 +183,10 @@ static int ensure_pool_capacity(svo_ctx *c, uint64_t need_len, bool keep) {
   uint64_t ncap = keep ? std::max<uint64_t>(need, c->pool_cap + c->pool_cap / 4) : need;
   uint8_t *np = nullptr;
   HIPCHK(c, hipMalloc((void **)&np, ncap));
-  HIPCHK(c, hipMemsetAsync(np, 0, ncap, c->stream));
+  HIPCHK(c, hipMemsetAsync(np, 0, ncap, c->own_stream));
   if (keep && c->d_pool && c->pool_len)
-    HIPCHK(c, hipMemcpyAsync(np, c->d_pool, c->pool_len, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(np, c->d_pool, c->pool_len, hipMemcpyDeviceToDevice, c->own_stream));
+  HIPCHK(c, hipStreamSynchronize(c->own_stream));
   if (c->d_pool) HIPCHK(c, hipFree(c->d_pool));   // callers have synchronised the device: no frame still reads it
   c->d_pool = np;
   c->pool_cap = ncap;
@@ -170,8 +207,8 @@ int svo_pool_reserve(svo_ctx *c, uint64_t nbytes) {
   HIPCHK(c, hipDeviceSynchronize());
   int rc = ensure_pool_capacity(c, nbytes, false);
   if (rc) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_pool, 0, c->pool_cap, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_pool, 0, c->pool_cap, c->own_stream));
+  HIPCHK(c, hipStreamSynchronize(c->own_stream));
   c->pool_len = nbytes;
   return SVO_OK;
 }
@@ -267,20 +304,20 @@ int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *
   hipError_t e = hipMalloc((void **)&d_h, cells * 2);
   if (e == hipSuccess) e = hipMalloc((void **)&d_m, cells);
   if (e == hipSuccess) e = hipMalloc((void **)&d_z, 4);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_h, height, cells * 2, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_m, material, cells, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(d_z, 0, 4, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_h, height, cells * 2, hipMemcpyHostToDevice, c->own_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_m, material, cells, hipMemcpyHostToDevice, c->own_stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_z, 0, 4, c->own_stream);
   unsigned int zeros = 0;
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(count_zero_bytes_kernel, dim3(1024), dim3(256), 0, c->stream, d_m, cells, d_z);
-    e = hipMemcpyAsync(&zeros, d_z, 4, hipMemcpyDeviceToHost, c->stream);
+    hipLaunchKernelGGL(count_zero_bytes_kernel, dim3(1024), dim3(256), 0, c->own_stream, d_m, cells, d_z);
+    e = hipMemcpyAsync(&zeros, d_z, 4, hipMemcpyDeviceToHost, c->own_stream);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
   if (e != hipSuccess) { cleanup(); return fail(c, SVO_E_HIP, std::string("svo_build_from_heightmap: ") + hipGetErrorString(e)); }
   if (zeros) { cleanup(); return fail(c, SVO_E_INVALID, "svo_build_from_heightmap: material 0 in the material map (0 is the empty voxel)"); }
   build::Result r;
   bool too_large = false;
-  e = build::build_pool(d_h, d_m, n, kPad, c->stream, r, &too_large);
+  e = build::build_pool(d_h, d_m, n, kPad, c->own_stream, r, &too_large);
   cleanup();
   if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_build_from_heightmap: ") + hipGetErrorString(e));
   if (too_large) {
@@ -302,10 +339,10 @@ int svo_build_from_voxels(svo_ctx *c, const uint8_t *voxels, int n, uint64_t *ou
   const size_t cells = (size_t)n * (size_t)n * (size_t)n;
   uint8_t *d_v = nullptr;
   hipError_t e = hipMalloc((void **)&d_v, cells);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_v, voxels, cells, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_v, voxels, cells, hipMemcpyHostToDevice, c->own_stream);
   build::Result r;
   bool too_large = false;
-  if (e == hipSuccess) e = build::build_pool_from_voxels(d_v, n, kPad, c->stream, r, &too_large);
+  if (e == hipSuccess) e = build::build_pool_from_voxels(d_v, n, kPad, c->own_stream, r, &too_large);
   if (d_v) (void)hipFree(d_v);
   if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_build_from_voxels: ") + hipGetErrorString(e));
   if (too_large) {
@@ -349,6 +386,9 @@ int svo_resize(svo_ctx *c, int width, int height) {
   HIPCHK(c, hipMemset(c->own_color, 0, n * 4));
   HIPCHK(c, hipMemset(c->own_depth, 0, n * 4));
   HIPCHK(c, hipMemset(c->own_hits, 0, n * 16));
+  // hipMemset is asynchronous and the dispatch streams do not synchronise with the null stream: without this wait the
+  // zeroing can land after the first frame's stores (seen as all-zero hit records of sky pixels)
+  HIPCHK(c, hipDeviceSynchronize());
   if (!c->external_outputs) { c->d_color = c->own_color; c->d_depth = c->own_depth; c->d_hits = c->own_hits; }
   c->width = width; c->height = height;
   c->y0 = 0; c->y1 = height; c->rows_set = false;  // a new image size resets the row band to the whole frame
@@ -448,13 +488,9 @@ int svo_set_stream(svo_ctx *c, void *hip_stream) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   // no synchronisation here: a caller may alternate streams to keep two frames in flight
-  // (different output buffers); ordering between streams is the caller's business
-  if (c->own_stream && c->stream) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamDestroy(c->stream));
-  }
-  c->stream = (hipStream_t)hip_stream;
-  c->own_stream = false;
+  // (different output buffers); ordering between streams is the caller's business.  The library's own stream lives as
+  // long as the context: NULL returns to it.
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return SVO_OK;
 }
 
@@ -549,7 +585,7 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
 static int ensure_derived(svo_ctx *c) {
   if (c->derived_valid) return SVO_OK;
   HIPCHK(c, hipDeviceSynchronize());
-  hipError_t e = derive::build_table(c->dt, c->d_pool, c->pool_len, c->stream);
+  hipError_t e = derive::build_table(c->dt, c->d_pool, c->pool_len, c->own_stream);
   if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("descriptor table: ") + hipGetErrorString(e));
   c->derived_valid = true;
   return SVO_OK;
@@ -688,6 +724,216 @@ int svo_time_frames(svo_ctx *c, int warmup, int iters, float *ms) {
   if (rc != SVO_OK) return rc;
   if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
   c->stats.last_dispatch_ms = ms[iters - 1];
+  return SVO_OK;
+}
+
+
+// ---------------------------------------------------------------- frames in flight behind the boundary
+int svo_ring_create(svo_ctx *c, int slots, int frames_per_slot, int want_hits) {
+  if (!c || slots < 1 || slots > 8 || frames_per_slot < 1 || frames_per_slot > 64)
+    return fail(c, SVO_E_INVALID, "svo_ring_create: 1..8 slots of 1..64 frames");
+  if (c->width <= 0 || c->height <= 0) return fail(c, SVO_E_INVALID, "svo_ring_create: svo_resize not called");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  ring_free(c);
+  const uint64_t stride = (uint64_t)c->width * (uint64_t)c->height;
+  if (stride * (uint64_t)frames_per_slot >= (1ull << 32)) return fail(c, SVO_E_INVALID, "svo_ring_create: slot too large for 32-bit output indices");
+  c->ring.resize((size_t)slots);
+  const size_t n = (size_t)stride * (size_t)frames_per_slot;
+  // CU mask of the slots' streams: bit i = CU i / 8 of XCD i % 8 (tools/cumask_probe.hip); the top 8 r bits cleared
+  // keep r CUs of every XCD free of persistent waves
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+  std::vector<uint32_t> cumask((size_t)(ncu + 31) / 32, 0xffffffffu);
+  const int reserve = std::min(c->reserved_cus * 8, ncu - 8);
+  for (int b = ncu - reserve; b < ncu && reserve > 0; b++) cumask[(size_t)b >> 5] &= ~(1u << (b & 31));
+  if (ncu & 31) cumask.back() &= (1u << (ncu & 31)) - 1u;
+  c->pb.cus_reserved = reserve > 0 ? reserve : 0;
+  for (auto &s : c->ring) {
+    hipError_t e = reserve > 0 ? hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)cumask.size(), cumask.data())
+                               : hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&s.e0);
+    if (e == hipSuccess) e = hipEventCreate(&s.e1);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.color, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.depth, n * 4);
+    if (e == hipSuccess && want_hits) e = hipMalloc((void **)&s.hits, n * 16);
+    if (e == hipSuccess) e = hipMemset(s.color, 0, n * 4);
+    if (e == hipSuccess) e = hipMemset(s.depth, 0, n * 4);
+    if (e == hipSuccess && want_hits) e = hipMemset(s.hits, 0, n * 16);
+    if (e != hipSuccess) {
+      ring_free(c);
+      return fail(c, SVO_E_HIP, std::string("svo_ring_create: ") + hipGetErrorString(e));
+    }
+  }
+  HIPCHK(c, hipDeviceSynchronize());   // the zeroing above is asynchronous; the slots' streams do not wait for the null stream
+  c->ring_frames = frames_per_slot;
+  c->ring_stride = stride;
+  return SVO_OK;
+}
+
+int svo_set_reserved_cus(svo_ctx *c, int per_xcd) {
+  if (!c || per_xcd < 0 || per_xcd > 16) return fail(c, SVO_E_INVALID, "svo_set_reserved_cus: 0..16 CUs per XCD");
+  c->reserved_cus = per_xcd;
+  return SVO_OK;
+}
+
+int svo_ring_destroy(svo_ctx *c) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  ring_free(c);
+  return SVO_OK;
+}
+
+static svo_ctx::RingSlot *ring_slot(svo_ctx *c, int slot, const char *who) {
+  if (!c) return nullptr;
+  if (slot < 0 || slot >= (int)c->ring.size()) {
+    (void)fail(c, SVO_E_INVALID, std::string(who) + ": no such slot (svo_ring_create first)");
+    return nullptr;
+  }
+  return &c->ring[(size_t)slot];
+}
+
+int svo_ring_bind_slot(svo_ctx *c, int slot, void *color, void *depth, void *hits, uint64_t frame_stride) {
+  svo_ctx::RingSlot *s = ring_slot(c, slot, "svo_ring_bind_slot");
+  if (!s) return SVO_E_INVALID;
+  if (color && (!depth || frame_stride == 0)) return fail(c, SVO_E_INVALID, "svo_ring_bind_slot: depth buffer and frame stride required");
+  if (color && frame_stride * (uint64_t)c->ring_frames >= (1ull << 32)) return fail(c, SVO_E_INVALID, "svo_ring_bind_slot: slot too large for 32-bit output indices");
+  s->xcolor = color; s->xdepth = color ? depth : nullptr; s->xhits = color ? hits : nullptr; s->xstride = color ? frame_stride : 0;
+  return SVO_OK;
+}
+
+int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
+  if (!c) return SVO_E_INVALID;
+  if (c->ring.empty()) return fail(c, SVO_E_INVALID, "svo_ring_submit: svo_ring_create first");
+  if (nframes < 1 || nframes > c->ring_frames) return fail(c, SVO_E_INVALID, "svo_ring_submit: 1..frames_per_slot frames");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int si = (int)(c->ring_next % (unsigned)c->ring.size());
+  svo_ctx::RingSlot &s = c->ring[(size_t)si];
+  // the dispatch state of the context, with this slot's stream, images and frame range swapped in
+  struct Saved {
+    hipStream_t stream; uint32_t *col; float *dep; uint4 *hit; bool ext; int batch; uint64_t stride; int frame;
+  } const sv = {c->stream, c->d_color, c->d_depth, c->d_hits, c->external_outputs, c->batch, c->frame_stride, c->frame_number};
+  c->stream = s.stream;
+  c->external_outputs = true;
+  if (s.xcolor) { c->d_color = (uint32_t *)s.xcolor; c->d_depth = (float *)s.xdepth; c->d_hits = (uint4 *)s.xhits; c->frame_stride = s.xstride; }
+  else { c->d_color = s.color; c->d_depth = s.depth; c->d_hits = s.hits; c->frame_stride = c->ring_stride; }
+  c->batch = nframes;
+  c->frame_number = frame_number;
+  int rc = SVO_OK;
+  hipError_t e = hipEventRecord(s.e0, s.stream);
+  if (e == hipSuccess) rc = launch_frame(c, false);
+  if (e == hipSuccess && rc == SVO_OK) e = hipEventRecord(s.e1, s.stream);
+  c->stream = sv.stream; c->d_color = sv.col; c->d_depth = sv.dep; c->d_hits = sv.hit; c->external_outputs = sv.ext;
+  c->batch = sv.batch; c->frame_stride = sv.stride; c->frame_number = sv.frame;
+  if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_ring_submit: ") + hipGetErrorString(e));
+  if (rc) return rc;
+  s.first_frame = frame_number; s.nframes = nframes; s.used = true;
+  c->ring_next++;
+  if (slot) *slot = si;
+  return SVO_OK;
+}
+
+int svo_ring_wait(svo_ctx *c, int slot) {
+  svo_ctx::RingSlot *s = ring_slot(c, slot, "svo_ring_wait");
+  if (!s) return SVO_E_INVALID;
+  if (!s->used) return SVO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(s->e1));
+  return SVO_OK;
+}
+
+int svo_ring_query(svo_ctx *c, int slot, int *done, int *first_frame, int *nframes, float *gpu_ms) {
+  svo_ctx::RingSlot *s = ring_slot(c, slot, "svo_ring_query");
+  if (!s) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  bool fin = true;
+  if (s->used) {
+    const hipError_t q = hipEventQuery(s->e1);
+    if (q == hipErrorNotReady) fin = false;
+    else if (q != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_ring_query: ") + hipGetErrorString(q));
+  }
+  if (done) *done = fin ? 1 : 0;
+  if (first_frame) *first_frame = s->first_frame;
+  if (nframes) *nframes = s->used ? s->nframes : 0;
+  if (gpu_ms) {
+    *gpu_ms = 0.0f;
+    if (s->used && fin) HIPCHK(c, hipEventElapsedTime(gpu_ms, s->e0, s->e1));
+  }
+  return SVO_OK;
+}
+
+// frame k of a slot: base pointers of its three images
+static int ring_frame(svo_ctx *c, int slot, int k, const char *who, const uint32_t **col, const float **dep, const uint4 **hit,
+                      size_t *elems = nullptr) {
+  svo_ctx::RingSlot *s = ring_slot(c, slot, who);
+  if (!s) return SVO_E_INVALID;
+  if (!s->used || k < 0 || k >= s->nframes) return fail(c, SVO_E_INVALID, std::string(who) + ": the slot does not hold that frame");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(s->e1));
+  const uint64_t stride = s->xcolor ? s->xstride : c->ring_stride;
+  const uint64_t o = (uint64_t)k * stride;
+  // a caller-owned slot may hold less than W x H elements per frame (packed stripes of one rank)
+  if (elems) *elems = (size_t)std::min<uint64_t>((uint64_t)c->width * (uint64_t)c->height, stride);
+  *col = (s->xcolor ? (const uint32_t *)s->xcolor : s->color) + o;
+  *dep = (s->xcolor ? (const float *)s->xdepth : s->depth) + o;
+  const uint4 *h = s->xcolor ? (const uint4 *)s->xhits : s->hits;
+  *hit = h ? h + o : nullptr;
+  return SVO_OK;
+}
+
+int svo_ring_read_color(svo_ctx *c, int slot, int k, void *rgba8) {
+  const uint32_t *col; const float *dep; const uint4 *hit;
+  if (!rgba8) return fail(c, SVO_E_INVALID, "readback: null buffer");
+  size_t n = 0;
+  int rc = ring_frame(c, slot, k, "svo_ring_read_color", &col, &dep, &hit, &n);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy(rgba8, col, n * 4, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+int svo_ring_read_depth(svo_ctx *c, int slot, int k, float *depth) {
+  const uint32_t *col; const float *dep; const uint4 *hit;
+  if (!depth) return fail(c, SVO_E_INVALID, "readback: null buffer");
+  size_t n = 0;
+  int rc = ring_frame(c, slot, k, "svo_ring_read_depth", &col, &dep, &hit, &n);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy(depth, dep, n * 4, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+int svo_ring_read_hits(svo_ctx *c, int slot, int k, svo_hit *hits) {
+  const uint32_t *col; const float *dep; const uint4 *hit;
+  if (!hits) return fail(c, SVO_E_INVALID, "readback: null buffer");
+  size_t n = 0;
+  int rc = ring_frame(c, slot, k, "svo_ring_read_hits", &col, &dep, &hit, &n);
+  if (rc) return rc;
+  if (!hit) return fail(c, SVO_E_INVALID, "svo_ring_read_hits: the ring was created without hit records");
+  HIPCHK(c, hipMemcpy(hits, hit, n * 16, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+int svo_ring_read_pixel(svo_ctx *c, int slot, int k, int x, int y, void *rgba8, float *depth, svo_hit *hit) {
+  const uint32_t *col; const float *dep; const uint4 *hp;
+  if (!c) return SVO_E_INVALID;
+  if (x < 0 || y < 0 || x >= c->width || y >= c->height) return fail(c, SVO_E_INVALID, "svo_ring_read_pixel: outside the image");
+  int rc = ring_frame(c, slot, k, "svo_ring_read_pixel", &col, &dep, &hp);
+  if (rc) return rc;
+  const size_t o = (size_t)y * (size_t)c->width + (size_t)x;
+  if (rgba8) HIPCHK(c, hipMemcpy(rgba8, col + o, 4, hipMemcpyDeviceToHost));
+  if (depth) HIPCHK(c, hipMemcpy(depth, dep + o, 4, hipMemcpyDeviceToHost));
+  if (hit) {
+    if (!hp) return fail(c, SVO_E_INVALID, "svo_ring_read_pixel: the ring was created without hit records");
+    HIPCHK(c, hipMemcpy(hit, hp + o, 16, hipMemcpyDeviceToHost));
+  }
+  return SVO_OK;
+}
+
+int svo_ring_device_ptrs(svo_ctx *c, int slot, void **color, void **depth, void **hits, uint64_t *frame_stride, void **stream) {
+  svo_ctx::RingSlot *s = ring_slot(c, slot, "svo_ring_device_ptrs");
+  if (!s) return SVO_E_INVALID;
+  if (color) *color = s->xcolor ? s->xcolor : (void *)s->color;
+  if (depth) *depth = s->xcolor ? s->xdepth : (void *)s->depth;
+  if (hits) *hits = s->xcolor ? s->xhits : (void *)s->hits;
+  if (frame_stride) *frame_stride = s->xcolor ? s->xstride : c->ring_stride;
+  if (stream) *stream = (void *)s->stream;
   return SVO_OK;
 }
 

@@ -79,4 +79,70 @@ jint Java_src_engine_HipRenderer_nSetProgressive(void *, void *, jlong ctx, jint
   return svo_set_progressive((svo_ctx *)(intptr_t)ctx, enabled);
 }
 
+
+#define CTX(x) ((svo_ctx *)(intptr_t)(x))
+jint Java_src_engine_HipRenderer_nDispatchAsync(void *, void *, jlong ctx) { return svo_dispatch_async(CTX(ctx)); }
+jint Java_src_engine_HipRenderer_nSync(void *, void *, jlong ctx) { return svo_sync(CTX(ctx)); }
+jint Java_src_engine_HipRenderer_nSetStream(void *, void *, jlong ctx, jlong hip_stream) {
+  return svo_set_stream(CTX(ctx), (void *)(intptr_t)hip_stream);
+}
+jint Java_src_engine_HipRenderer_nSetPipeline(void *, void *, jlong ctx, jint pipeline) { return svo_set_pipeline(CTX(ctx), pipeline); }
+jint Java_src_engine_HipRenderer_nSetTuning(void *, void *, jlong ctx, jint waves_per_cu, jint thresh) {
+  return svo_set_tuning(CTX(ctx), waves_per_cu, thresh);
+}
+jint Java_src_engine_HipRenderer_nSetDerived(void *, void *, jlong ctx, jint mode) { return svo_set_derived(CTX(ctx), mode); }
+jint Java_src_engine_HipRenderer_nSetHitRecords(void *, void *, jlong ctx, jint enabled) { return svo_set_hit_records(CTX(ctx), enabled); }
+jint Java_src_engine_HipRenderer_nSetRows(void *, void *, jlong ctx, jint y0, jint y1) { return svo_set_rows(CTX(ctx), y0, y1); }
+jint Java_src_engine_HipRenderer_nSetStripes(void *, void *, jlong ctx, jint first_tile_row, jint tile_row_step, jint n_tile_rows,
+                                             jint out_row0) {
+  return svo_set_stripes(CTX(ctx), first_tile_row, tile_row_step, n_tile_rows, out_row0);
+}
+jint Java_src_engine_HipRenderer_nCountFrame(void *, void *, jlong ctx, jlong stats_addr) {
+  return svo_count_frame(CTX(ctx), (svo_stats *)(intptr_t)stats_addr);
+}
+jint Java_src_engine_HipRenderer_nGetStats(void *, void *, jlong ctx, jlong stats_addr) {
+  return svo_get_stats(CTX(ctx), (svo_stats *)(intptr_t)stats_addr);
+}
+jlong Java_src_engine_HipRenderer_nDerivedInfo(void *, void *, jlong ctx, jlong walkable_addr) {
+  uint64_t n = 0;
+  const int rc = svo_derived_info(CTX(ctx), &n, nullptr, (int *)(intptr_t)walkable_addr, nullptr);
+  return rc == SVO_OK ? (jlong)n : (jlong)rc;
+}
+jint Java_src_engine_HipRenderer_nRingCreate(void *, void *, jlong ctx, jint slots, jint frames_per_slot, jint want_hits) {
+  return svo_ring_create(CTX(ctx), slots, frames_per_slot, want_hits);
+}
+jint Java_src_engine_HipRenderer_nRingDestroy(void *, void *, jlong ctx) { return svo_ring_destroy(CTX(ctx)); }
+jint Java_src_engine_HipRenderer_nRingSubmit(void *, void *, jlong ctx, jint frame_number, jint nframes) {
+  int slot = -1;
+  const int rc = svo_ring_submit(CTX(ctx), frame_number, nframes, &slot);
+  return rc == SVO_OK ? slot : rc;
+}
+jint Java_src_engine_HipRenderer_nRingWait(void *, void *, jlong ctx, jint slot) { return svo_ring_wait(CTX(ctx), slot); }
+jint Java_src_engine_HipRenderer_nRingDone(void *, void *, jlong ctx, jint slot, jlong ms_addr) {
+  int done = 0;
+  const int rc = svo_ring_query(CTX(ctx), slot, &done, nullptr, nullptr, (float *)(intptr_t)ms_addr);
+  return rc == SVO_OK ? done : rc;
+}
+jint Java_src_engine_HipRenderer_nRingReadColor(void *, void *, jlong ctx, jint slot, jint k, jlong addr) {
+  return svo_ring_read_color(CTX(ctx), slot, k, (void *)(intptr_t)addr);
+}
+jint Java_src_engine_HipRenderer_nRingReadDepth(void *, void *, jlong ctx, jint slot, jint k, jlong addr) {
+  return svo_ring_read_depth(CTX(ctx), slot, k, (float *)(intptr_t)addr);
+}
+jint Java_src_engine_HipRenderer_nRingReadHits(void *, void *, jlong ctx, jint slot, jint k, jlong addr) {
+  return svo_ring_read_hits(CTX(ctx), slot, k, (svo_hit *)(intptr_t)addr);
+}
+jint Java_src_engine_HipRenderer_nRingReadPixel(void *, void *, jlong ctx, jint slot, jint k, jint x, jint y, jlong rgba_addr,
+                                                jlong depth_addr, jlong hit_addr) {
+  return svo_ring_read_pixel(CTX(ctx), slot, k, x, y, (void *)(intptr_t)rgba_addr, (float *)(intptr_t)depth_addr,
+                             (svo_hit *)(intptr_t)hit_addr);
+}
+jint Java_src_engine_HipRenderer_nRingBindSlot(void *, void *, jlong ctx, jint slot, jlong color_dptr, jlong depth_dptr,
+                                               jlong hits_dptr, jlong frame_stride) {
+  if (frame_stride < 0) return SVO_E_INVALID;
+  return svo_ring_bind_slot(CTX(ctx), slot, (void *)(intptr_t)color_dptr, (void *)(intptr_t)depth_dptr, (void *)(intptr_t)hits_dptr,
+                            (uint64_t)frame_stride);
+}
+#undef CTX
+
 }  // extern "C"

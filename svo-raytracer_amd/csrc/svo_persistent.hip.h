@@ -497,6 +497,7 @@ struct PersistBuffers {
   int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/history/sweep8.sh)
   int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
   int max_per_cu = 16, max_per_cu_desc = 16, cus = 256;   // resident waves per CU: byte walk / descriptor walk
+  int cus_reserved = 0;   // CUs the launching stream may not use (svo_set_reserved_cus): fewer persistent waves
   unsigned launches = 0, frames = 0;
 };
 
@@ -572,7 +573,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   }
   {
     int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (desc ? b.max_per_cu_desc : b.max_per_cu);
-    b.blocks = b.cus * per_cu;
+    b.blocks = (b.cus - b.cus_reserved) * per_cu;
   }
   const int spp = f.spp < 1 ? 1 : f.spp;
   const bool resolve = spp > 1 || f.progressive;   // colours go through the float planes and the resolve kernel

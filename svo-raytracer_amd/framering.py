@@ -13,8 +13,16 @@ planes = colour (rgba8), depth (f32 bits) [+ 4 words of hit record]; `batch` = f
 with out_row0 = 0, outputs bound at the chunk, frame k of the batch rows_per_rank * W elements further), so one
 contiguous chunk per rank and ONE gather per dispatch carry colour and depth of all its frames together.
 
+Streams, launch events and the submission itself belong to the library's own ring (include/svo_hip.h, svo_ring_*:
+one slot per dispatch in flight, a HIP stream of its own per slot); what stays here is what torch is needed for --
+the gather buffers RCCL reads in place (bound to the slots with svo_ring_bind_slot), the gather on a communication
+stream ordered against the slots' streams, and the de-interleave on the frame owner.  With one rank and no what-if
+layout nothing is bound: the slots render into the library's own images and frames are read back through
+svo_ring_read_*.
+
 The renderer is duck-typed (hiplib.HipContext on the GPU; tests pass a CPU stand-in):
-  set_stream(ptr) bind_outputs(color_ptr, depth_ptr, hits_ptr) set_params(...) set_batch(n, stride) dispatch_async()
+  set_stripes(...) set_params(...) ring_create(slots, frames, want_hits) ring_bind_slot(slot, c, d, h, stride)
+  ring_submit(frame, n) -> slot  ring_wait(slot)  ring_query(slot)  ring_device_ptrs(slot)  ring_read(slot, k, want_hits)
 """
 import torch
 
@@ -61,33 +69,46 @@ class FrameRing:
         self.s_first, self.s_step, self.s_n, _, self.rows_per_rank = stripe_layout(self.H, lw, lr)
         self.chunk_world = self.world if as_rank is None else 1
         rpr = self.rows_per_rank
-        # [world][planes][batch][rpr][W] words; rank r's chunk is self.buf[b][r]
-        self.buf = [torch.zeros((self.chunk_world, self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
-                    for _ in range(self.nbuf)]
-        self.frame_of = [None] * self.nbuf          # first frameNumber held by each buffer
+        # the library's ring: one slot per dispatch in flight
+        if hasattr(self.r, "set_stripes"):
+            self.r.set_stripes(self.s_first, self.s_step, self.s_n, 0)
+        p = self.params
+        self.r.set_params(self.first_frame, p["render_mode"], p["buffer_end"], p["use_beam"], p["bounces"], p["mirror_mask"], p["spp"])
+        self.r.ring_create(self.nbuf, self.batch, want_hits)
+        # torch-owned gather buffers, [world][planes][batch][rpr][W] words; rank r's chunk is self.buf[b][r].  Not needed
+        # (library-owned images instead) when this process renders whole frames for itself.
+        self.own_images = (not self.use_comm) and as_rank is None and self.world == 1
+        self.buf = None if self.own_images else [
+            torch.zeros((self.chunk_world, self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
+            for _ in range(self.nbuf)]
+        self.frame_of = [None] * self.nbuf          # first frameNumber held by each slot
         self.count_of = [0] * self.nbuf             # frames it holds
         self.scratch = (torch.zeros((self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
                         if self.use_comm and self.rank == 0 else None)
+        self.my_chunk = self.rank if as_rank is None else 0
         if self.cuda:
-            # one stream of its own per dispatch in flight (not torch's default stream).  HIP maps streams onto a small
-            # number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default): two of these streams on one queue serialise
-            # their launches (3.6 instead of 4.5 Grays/s, tools/history/r02_streams.sh), so the process should raise the limit
-            # before it touches the GPU -- bench.py sets GPU_MAX_HW_QUEUES=8.
-            main = torch.cuda.current_stream()
-            self.streams = [torch.cuda.Stream() for _ in range(self.nbuf)]
-            for s in self.streams:
-                s.wait_stream(main)
-            self.comm_stream = torch.cuda.Stream() if self.use_comm else None
+            torch.cuda.synchronize()                # the buffers are zeroed before a slot's stream writes them
+        if self.buf is not None:
+            for b in range(self.nbuf):
+                c, d, h = self._ptrs(b)
+                self.r.ring_bind_slot(b, c, d, h, rpr * self.W)
+        if self.cuda and self.use_comm:
+            # the slots' streams, wrapped so that torch events can order the gather against them.  HIP maps streams onto
+            # a small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default): two frame streams on one queue
+            # serialise their launches (3.6 instead of 4.5 Grays/s, tools/history/r02_streams.sh) -- bench.py sets 8
+            # before it touches the GPU, svo_create does when it comes first.
+            self.streams = [torch.cuda.ExternalStream(self.r.ring_device_ptrs(b)["stream"]) for b in range(self.nbuf)]
+            self.comm_stream = torch.cuda.Stream()
         else:
             self.streams = [_NoStream() for _ in range(self.nbuf)]
             self.comm_stream = _NoStream() if self.use_comm else None
         self.gathered = [None] * self.nbuf          # event: the gather that last read buffer b has finished
         self.timing = False
-        self.launch_events = []
+        self.launch_ms = []                         # (GPU ms, frames) of every timed submission (svo_ring_query)
+        self.timed_of = [False] * self.nbuf
+        import os
+        self.host_wait = os.environ.get("SVO_RING_HOST_WAIT", "1") != "0"   # experiment knob
         self.dispatches = 0
-        self.my_chunk = self.rank if as_rank is None else 0
-        if hasattr(self.r, "set_stripes"):
-            self.r.set_stripes(self.s_first, self.s_step, self.s_n, 0)
 
     # ---- one frame ------------------------------------------------------------------------------
     def _ptrs(self, b):
@@ -98,35 +119,27 @@ class FrameRing:
         return base, base + plane, (base + 2 * plane if self.want_hits else None)
 
     def step(self, nframes=None):
-        """Dispatch the next `nframes` frames (default: a whole batch) as one dispatch; returns the first frameNumber."""
+        """Submit the next `nframes` frames (default: a whole batch) as one dispatch; returns the first frameNumber."""
         n = self.batch if nframes is None else max(1, min(int(nframes), self.batch))
         b = self.dispatches % self.nbuf
-        self.dispatches += 1
         frame = self.first_frame + self.k
+        # a slot is re-used once its previous frames are complete (a host that reads them has waited for them anyway);
+        # the other nbuf - 1 submissions keep the GPU busy meanwhile
+        if self.dispatches >= self.nbuf and self.host_wait:
+            self.r.ring_wait(b)
+            if self.timing and self.timed_of[b]:
+                self.launch_ms.append((self.r.ring_query(b)["gpu_ms"], self.count_of[b]))
+        self.dispatches += 1
         self.k += n
-        stream = self.streams[b]
-        self.r.set_stream(stream.cuda_stream)
         if self.gathered[b] is not None:
-            stream.wait_event(self.gathered[b])
-        c, d, h = self._ptrs(b)
-        self.r.bind_outputs(c, d, h)
-        p = self.params
-        self.r.set_params(frame, p["render_mode"], p["buffer_end"], p["use_beam"], p["bounces"], p["mirror_mask"], p["spp"])
-        if self.batch > 1 or hasattr(self.r, "set_batch"):
-            self.r.set_batch(n, self.rows_per_rank * self.W)
+            self.streams[b].wait_event(self.gathered[b])
+        slot = self.r.ring_submit(frame, n)
+        assert slot == b, (slot, b)
         self.frame_of[b] = frame
         self.count_of[b] = n
-        if self.timing and self.cuda:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            self.r.dispatch_async()
-            e1.record(stream)
-            self.launch_events.append((e0, e1))
-        else:
-            self.r.dispatch_async()
+        self.timed_of[b] = self.timing
         if self.use_comm:
-            self._gather(b, stream)
+            self._gather(b, self.streams[b])
         return frame
 
     def _gather(self, b, stream):
@@ -157,13 +170,24 @@ class FrameRing:
 
     # ---- after the run ----------------------------------------------------------------------------
     def drain(self):
+        for b in range(min(self.nbuf, self.dispatches)):
+            self.r.ring_wait(b)
+            if self.timed_of[b]:
+                self.launch_ms.append((self.r.ring_query(b)["gpu_ms"], self.count_of[b]))
+                self.timed_of[b] = False
         if self.cuda:
             torch.cuda.synchronize()
-            self.r.set_stream(self.streams[0].cuda_stream)
 
     def frame_images(self, b, k=0):
         """(frameNumber, colour [H][W] int32, depth [H][W] float32[, hits [H][W][4] int32]) of frame k of buffer b in
         frame order, on the frame owner (rank 0) after drain(); with as_rank only the rows that rank rendered are valid."""
+        if self.own_images:                     # whole frames in the library's own images: read back through the ring
+            img = self.r.ring_read(b, k, want_hits=self.want_hits)
+            out = (self.frame_of[b] + k, torch.from_numpy(img["rgba"].view("<i4").reshape(self.H, self.W)),
+                   torch.from_numpy(img["depth"]))
+            if self.want_hits:
+                out = out + (torch.from_numpy(img["hits"].view("<i4").reshape(self.H, self.W, 4)),)
+            return out
         full = self.buf[b][:, :, k]             # [chunks][planes][rpr][W]
         per = self.rows_per_rank // TILE
         cw = full.shape[0]

@@ -18,6 +18,9 @@ EXPORTS = [
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_set_batch", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel", "svo_read_beam",
     "svo_output_device_ptrs", "svo_set_derived", "svo_derived_info",
+    "svo_ring_create", "svo_ring_destroy", "svo_ring_submit", "svo_ring_wait", "svo_ring_query", "svo_ring_read_color",
+    "svo_ring_read_depth", "svo_ring_read_hits", "svo_ring_read_pixel", "svo_ring_bind_slot", "svo_ring_device_ptrs",
+    "svo_set_reserved_cus",
 ]
 
 
@@ -72,6 +75,20 @@ def lib(path=None):
         L.svo_set_progressive.argtypes = [vp, ci]
         L.svo_set_batch.argtypes = [vp, ci, u64]
         L.svo_set_tuning.argtypes = [vp, ci, ci]
+        ip = ctypes.POINTER(ci)
+        L.svo_ring_create.argtypes = [vp, ci, ci, ci]
+        L.svo_ring_destroy.argtypes = [vp]
+        L.svo_set_reserved_cus.argtypes = [vp, ci]
+        L.svo_ring_submit.argtypes = [vp, ci, ci, ip]
+        L.svo_ring_wait.argtypes = [vp, ci]
+        L.svo_ring_query.argtypes = [vp, ci, ip, ip, ip, fp]
+        L.svo_ring_read_color.argtypes = [vp, ci, ci, vp]
+        L.svo_ring_read_depth.argtypes = [vp, ci, ci, vp]
+        L.svo_ring_read_hits.argtypes = [vp, ci, ci, vp]
+        L.svo_ring_read_pixel.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
+        L.svo_ring_bind_slot.argtypes = [vp, ci, vp, vp, vp, u64]
+        L.svo_ring_device_ptrs.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                           ctypes.POINTER(u64), ctypes.POINTER(vp)]
         L.svo_set_derived.argtypes = [vp, ci]
         L.svo_derived_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ci), fp]
         L.svo_dispatch.argtypes = [vp]
@@ -221,7 +238,59 @@ class HipContext:
         self._chk(self._L.svo_set_hit_records(self._h, 1 if on else 0))
 
     def set_stream(self, stream_ptr):
-        self._chk(self._L.svo_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+        self._chk(self._L.svo_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    # frames in flight behind the boundary (svo_ring_*)
+    def ring_create(self, slots, frames_per_slot=1, want_hits=False):
+        self._chk(self._L.svo_ring_create(self._h, int(slots), int(frames_per_slot), 1 if want_hits else 0))
+
+    def set_reserved_cus(self, per_xcd):
+        self._chk(self._L.svo_set_reserved_cus(self._h, int(per_xcd)))
+
+    def ring_destroy(self):
+        self._chk(self._L.svo_ring_destroy(self._h))
+
+    def ring_submit(self, frame_number, nframes=1):
+        slot = ctypes.c_int()
+        self._chk(self._L.svo_ring_submit(self._h, int(frame_number), int(nframes), ctypes.byref(slot)))
+        return int(slot.value)
+
+    def ring_wait(self, slot):
+        self._chk(self._L.svo_ring_wait(self._h, int(slot)))
+
+    def ring_query(self, slot):
+        done, first, n, ms = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_float()
+        self._chk(self._L.svo_ring_query(self._h, int(slot), ctypes.byref(done), ctypes.byref(first), ctypes.byref(n), ctypes.byref(ms)))
+        return {"done": bool(done.value), "first_frame": int(first.value), "nframes": int(n.value), "gpu_ms": float(ms.value)}
+
+    def ring_read(self, slot, k=0, want_hits=False):
+        out = {"rgba": np.zeros((self.height, self.width, 4), dtype=np.uint8),
+               "depth": np.zeros((self.height, self.width), dtype=np.float32)}
+        self._chk(self._L.svo_ring_read_color(self._h, int(slot), int(k), out["rgba"].ctypes.data))
+        self._chk(self._L.svo_ring_read_depth(self._h, int(slot), int(k), out["depth"].ctypes.data))
+        if want_hits:
+            out["hits"] = np.zeros((self.height, self.width), dtype=HIT_DTYPE)
+            self._chk(self._L.svo_ring_read_hits(self._h, int(slot), int(k), out["hits"].ctypes.data))
+        return out
+
+    def ring_read_pixel(self, slot, k, x, y, want_hit=True):
+        rgba = np.zeros(4, dtype=np.uint8)
+        depth = np.zeros(1, dtype=np.float32)
+        hit = np.zeros(1, dtype=HIT_DTYPE)
+        self._chk(self._L.svo_ring_read_pixel(self._h, int(slot), int(k), int(x), int(y), rgba.ctypes.data, depth.ctypes.data,
+                                              hit.ctypes.data if want_hit else None))
+        return rgba, float(depth[0]), hit[0]
+
+    def ring_bind_slot(self, slot, color_ptr, depth_ptr, hits_ptr, frame_stride):
+        self._chk(self._L.svo_ring_bind_slot(self._h, int(slot), ctypes.c_void_p(color_ptr or 0), ctypes.c_void_p(depth_ptr or 0),
+                                             ctypes.c_void_p(hits_ptr or 0), int(frame_stride)))
+
+    def ring_device_ptrs(self, slot):
+        a, b, c, st = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        n = ctypes.c_uint64()
+        self._chk(self._L.svo_ring_device_ptrs(self._h, int(slot), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c),
+                                               ctypes.byref(n), ctypes.byref(st)))
+        return {"color": a.value, "depth": b.value, "hits": c.value, "frame_stride": int(n.value), "stream": st.value}
 
     # dispatch
     def dispatch(self):

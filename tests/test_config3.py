@@ -150,3 +150,77 @@ def test_config3_as_the_benchmark_runs_it(pool8192):
         ctx.set_batch(1, 0)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_config3_through_the_jni_ring(pool8192):
+    """The same throughput configuration behind the drop-in boundary: JNI-typed calls only (what HipRenderer.java's
+    createFrameRing / submitFrames / readFrame make) -- a library-owned ring of 4 slots x 5 frames, four submissions in
+    flight, the golden frames 2 and 57 read back out of their slots; no torch stream or tensor involved."""
+    import ctypes
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    L = hiplib.lib()
+    vp, jint, jlong, jfloat = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    P = "Java_src_engine_HipRenderer_"
+
+    def fn(name, res, *args):
+        f = getattr(L, P + name)
+        f.restype = res
+        f.argtypes = [vp, vp] + list(args)
+        return lambda *a: f(None, None, *a)
+
+    nCreate, nDestroy = fn("nCreate", jlong, jint), fn("nDestroy", jint, jlong)
+    nPoolUpload = fn("nPoolUpload", jint, jlong, jlong, jlong)
+    nSetCamera = fn("nSetCamera", jint, jlong, *([jfloat] * 15))
+    nSetParams = fn("nSetParams", jint, jlong, *([jint] * 7))
+    nResize = fn("nResize", jint, jlong, jint, jint)
+    nSetPipeline, nSetTuning = fn("nSetPipeline", jint, jlong, jint), fn("nSetTuning", jint, jlong, jint, jint)
+    nRingCreate = fn("nRingCreate", jint, jlong, jint, jint, jint)
+    nRingSubmit = fn("nRingSubmit", jint, jlong, jint, jint)
+    nRingWait, nRingDone = fn("nRingWait", jint, jlong, jint), fn("nRingDone", jint, jlong, jint, jlong)
+    nRingReadColor = fn("nRingReadColor", jint, jlong, jint, jint, jlong)
+    nRingReadDepth = fn("nRingReadDepth", jint, jlong, jint, jint, jlong)
+    nRingReadHits = fn("nRingReadHits", jint, jlong, jint, jint, jlong)
+    nRingReadPixel = fn("nRingReadPixel", jint, jlong, jint, jint, jint, jint, jlong, jlong, jlong)
+    nRingDestroy = fn("nRingDestroy", jint, jlong)
+    nDerivedInfo = fn("nDerivedInfo", jlong, jlong, jlong)
+
+    z = np.load(GOLD)
+    step = int(z["step"][0])
+    w, h, nd, nb = 1920, 1080, 4, 5
+    j = nCreate(0)
+    assert j != 0
+    try:
+        assert nPoolUpload(j, pool8192.ctypes.data, pool8192.size) == 0
+        assert nSetPipeline(j, 1) == 0 and nSetTuning(j, 10, 9) == 0
+        assert nSetCamera(j, *[float(v) for v in np.asarray(CAMERAS["K1"], np.float32).reshape(-1)]) == 0
+        assert nRingSubmit(j, 2, 1) < 0                       # no ring yet
+        assert nResize(j, w, h) == 0
+        assert nRingCreate(j, nd, nb, 1) == 0
+        walk = ctypes.c_int32(-1)
+        assert nDerivedInfo(j, ctypes.addressof(walk)) > 1000 and walk.value == 1   # the bench scene takes the table walk
+        assert nSetParams(j, 2, 0, int(pool8192.size), 0, 2, 0, 1) == 0
+        assert nRingSubmit(j, 2, nb + 1) < 0                  # more frames than a slot holds
+        for first, want in ((2, ("c3_f2", 2)), (42, ("c3_f57", 57))):
+            slots = [nRingSubmit(j, first + b * nb, nb) for b in range(nd)]
+            assert slots == list(range(nd)) or sorted(slots) == list(range(nd)), slots
+            b, k = divmod(want[1] - first, nb)
+            ms = ctypes.c_float(0)
+            assert nRingWait(j, slots[b]) == 0 and nRingDone(j, slots[b], ctypes.addressof(ms)) == 1 and ms.value > 0
+            rgba = np.zeros((h, w, 4), np.uint8)
+            depth = np.zeros((h, w), np.float32)
+            hits = np.zeros((h, w), hiplib.HIT_DTYPE)
+            assert nRingReadColor(j, slots[b], k, rgba.ctypes.data) == 0
+            assert nRingReadDepth(j, slots[b], k, depth.ctypes.data) == 0
+            assert nRingReadHits(j, slots[b], k, hits.ctypes.data) == 0
+            _check({"rgba": rgba, "depth": depth, "hits": hits}, z, want[0], step)
+            one_d = np.zeros(1, np.float32)                    # the crosshair pick on a frame of the ring
+            assert nRingReadPixel(j, slots[b], k, 960, 540, 0, one_d.ctypes.data, 0) == 0
+            assert one_d.view(np.uint32)[0] == depth.view(np.uint32)[540, 960]
+            assert nRingReadColor(j, slots[b], nb, rgba.ctypes.data) < 0      # the slot holds frames 0..nb-1
+            for s in slots:
+                assert nRingWait(j, s) == 0
+        assert nRingDestroy(j) == 0
+    finally:
+        assert nDestroy(j) == 0

@@ -18,35 +18,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleStripeRenderer:
-    """Duck-types the part of hiplib.HipContext that FrameRing drives."""
+    """Duck-types the part of hiplib.HipContext that FrameRing drives: the svo_ring_* calls, with caller-owned slots
+    (the ring's own images only matter on the GPU)."""
 
     def __init__(self, pool, w, h, cam):
         self.pool, self.w, self.h, self.cam = pool, w, h, cam
         self.stripes = (0, 1, (h + 7) // 8, 0)
-        self.ptrs = None
         self.params = None
         self.calls = []
-        self.batch, self.frame_stride = 1, 0
-
-    def set_batch(self, n, stride):
-        self.batch, self.frame_stride = n, stride
+        self.slots, self.per, self.next = [], 0, 0
 
     def set_stripes(self, first, step, n, out0):
         self.stripes = (first, step, n, out0)
 
-    def set_stream(self, ptr):
-        pass
-
-    def bind_outputs(self, c, d, h):
-        self.ptrs = (c, d, h)
-
     def set_params(self, frame, mode, buffer_end, use_beam, bounces, mirror, spp):
         self.params = (frame, mode, bounces, mirror, spp)
 
-    def dispatch_async(self):
-        from oracle import oracle
-        for k in range(self.batch):        # frame k of the batch: frameNumber + k, outputs frame_stride elements further
-            self._one(self.params[0] + k, k * self.frame_stride)
+    def ring_create(self, slots, frames_per_slot, want_hits):
+        self.slots = [None] * slots
+        self.per, self.next = frames_per_slot, 0
+
+    def ring_bind_slot(self, slot, c, d, h, stride):
+        self.slots[slot] = (c, d, h, stride)
+
+    def ring_submit(self, frame, n):
+        assert 1 <= n <= self.per
+        slot = self.next % len(self.slots)
+        self.next += 1
+        c, d, h, stride = self.slots[slot]
+        self.ptrs = (c, d, h)
+        for k in range(n):        # frame k of the submission: frameNumber + k, outputs `stride` elements further
+            self._one(frame + k, k * stride)
+        return slot
+
+    def ring_wait(self, slot):
+        pass
+
+    def ring_query(self, slot):
+        return {"done": True, "gpu_ms": 0.0}
+
+    def ring_device_ptrs(self, slot):
+        return {"stream": 0}
 
     def _one(self, frame, eoff):
         from oracle import oracle

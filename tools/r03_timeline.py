@@ -28,6 +28,7 @@ for wpc in (8, 10, 14, 20):
         mix = [(d[12 + i] & 0xffffffff, d[12 + i] >> 32) for i in range(4)]
         if frame == 2 and mix[0][0]:
             t = mix[0][0]
+            print("  trips per frame %d (%.0f per wave), lane-iterations %d, rounds per wave %.1f" % (t, t / nw, mix[0][1], d[2] / nw))
             print("  per wave-trip: active lanes %.1f | descend section in %.1f %% of trips with %.1f lanes | advance %.1f %% with %.1f | pop %.1f %% with %.1f"
                   % (mix[0][1] / t, 100.0 * mix[1][0] / t, mix[1][1] / max(1, mix[1][0]), 100.0 * mix[2][0] / t, mix[2][1] / max(1, mix[2][0]),
                      100.0 * mix[3][0] / t, mix[3][1] / max(1, mix[3][0])))
