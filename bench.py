@@ -153,8 +153,8 @@ def launch_ranks(args):
     return subprocess.call(cmd)
 
 
-KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop.h", "svo_trav.h", "svo_device.h", "svo_fused.hip.h",
-                  "svo_kernels.h", "Makefile")
+KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop2.h", "svo_trav2.h", "svo_derive.hip.h", "svo_travloop.h", "svo_trav.h",
+                  "svo_device.h", "svo_fused.hip.h", "svo_kernels.h", "Makefile")
 
 
 def source_hash():
@@ -204,8 +204,13 @@ def pmc_for(key):
     return e
 
 
-def main():
-    args = parse()
+def main(argv=None, ctx_factory=None):
+    """ctx_factory: tests only -- a callable(local_rank) returning a CPU stand-in for hiplib.HipContext; the whole of main()
+    then runs on CPU tensors under gloo (tests/test_bench_main_gloo.py), exercising the sharding, counting, timing
+    protocol and the JSON line without a GPU.  The product path has no such fallback: without it a GPU is required."""
+    args = parse(argv)
+    stub = ctx_factory is not None
+    dev = "cpu" if stub else "cuda"
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
     # the dispatches in flight, the gather and torch's own stream each want a hardware queue of their own; HIP's default
@@ -219,12 +224,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SVO hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    if not stub:
+        torch.cuda.set_device(local_rank)
     force_comm = os.environ.get("SVO_BENCH_FORCE_COMM", "0") == "1"  # exercise the RCCL path on one GPU
-    if world > 1 or (force_comm and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if (world > 1 or (force_comm and "RANK" in os.environ)) and not dist.is_initialized():
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     use_comm = world > 1 or (force_comm and dist.is_initialized())
 
     import svo_raytracer_amd.scene as scene
@@ -234,7 +248,7 @@ def main():
 
     W, H = args.width, args.height
     cam = CAMERAS[args.camera]
-    ctx = hiplib.HipContext(local_rank)
+    ctx = ctx_factory(local_rank) if stub else hiplib.HipContext(local_rank)
 
     # ---- scene: built once on rank 0 (height / material maps on the host cores, the pool on the GPU by
     # svo_build_from_heightmap), replicated by one RCCL broadcast ------------------------------------------
@@ -247,13 +261,14 @@ def main():
         del hmap, mmap
         pool = ctx.pool_download(nbytes)     # host copy: source of the broadcast, and what the oracle checks against
     if world > 1:
-        dpool = replicate_pool(dist, pool, rank, world)
+        dpool = replicate_pool(dist, pool, rank, world, device=dev)
         nbytes = int(dpool.numel())
-        torch.cuda.synchronize()
+        sync()
         if rank != 0:
             ctx.pool_upload_device(dpool.data_ptr(), nbytes)
         del dpool
-        torch.cuda.empty_cache()
+        if not stub:
+            torch.cuda.empty_cache()
     if rank != 0:
         t_build = time.time() - t_build
 
@@ -274,7 +289,7 @@ def main():
     ctx.set_reserved_cus(comm_cus)
     params = dict(render_mode=args.mode, buffer_end=nbytes, use_beam=args.beam, bounces=args.bounces,
                   mirror_mask=args.mirror, spp=args.spp)
-    ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device="cuda",
+    ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device=dev,
                      dist=dist if use_comm else None, want_hits=bool(args.hits), force_comm=force_comm,
                      first_frame=2, params=params, as_rank=as_rank, batch=batch)
 
@@ -286,10 +301,13 @@ def main():
 
     first_timed = 2 + args.warmup
     last_timed = first_timed + args.steps - 1
-    ca, cb = count(first_timed), count(last_timed)
+    # every timed frame of a short run; of a long one, nine frames spread over it (first and last included)
+    counted = list(range(first_timed, last_timed + 1)) if args.steps <= 40 else \
+        sorted({first_timed + (args.steps - 1) * i // 8 for i in range(9)})
+    cs = [count(fr) for fr in counted]
     keys = ("rays", "iterations", "alg_bytes", "pixels", "nan_rays")
-    mine = [(ca[k] + cb[k]) / 2.0 for k in keys]
-    counts = torch.tensor(mine, dtype=torch.float64, device="cuda")
+    mine = [sum(c[k] for c in cs) / float(len(cs)) for k in keys]
+    counts = torch.tensor(mine, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(counts)
     rays, iters, alg_bytes, pixels, nan_rays = [float(v) for v in counts.tolist()]
@@ -303,20 +321,22 @@ def main():
     run_frames(args.warmup)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     ring.timing = True
     t0 = time.perf_counter()
     run_frames(args.steps)
-    torch.cuda.synchronize()
+    sync()
     ring.timing = False
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]     # every rank's own ms per step: min / max go on the line next to the MAX that counts
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tall = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([elapsed], dtype=torch.float64, device=dev))
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in tall]
+        elapsed = max(float(t.item()) for t in tall)
 
     # ---- the frames the ring still holds: the last nbuf timed frames, rendered with nbuf launches in flight ----
     ring.drain()
@@ -398,12 +418,21 @@ def main():
         stripes = "%d GPU(s) x interleaved tile rows (%d pixel rows each), gathered to rank 0" % (world, ring.rows_per_rank)
         if as_rank:
             stripes = "what-if: the stripes of rank %d of %d on one GPU, no communication" % as_rank
+        # the same frame through the reference's own loop -- one dispatch, then the crosshair read-back, then the next
+        # (Main.updateEarly, Main.java:132-146, 257-289): what `value` would be without frames in flight
+        one_at_a_time = (rays / (kernel_ms_isolated * 1e-3) / 1e6) if (kernel_ms_isolated and world == 1 and as_rank is None) else None
         line = {
             "metric": "Mrays/s (primary + 1 bounce) at 1920x1080, 8192^3 SVO",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "verified": verified,
+            "frames_in_flight": nbuf * batch,
+            "value_one_frame_at_a_time": round(one_at_a_time, 2) if one_at_a_time else None,
+            "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
+            "gather_ms": ring.gather_ms(),
+            "comm_cus_per_xcd": comm_cus,
             "config": {
                 "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %d spp, camera %s, "
                             "frameNumber %d..%d (one per step), pipeline %d, %s" % (
@@ -464,8 +493,11 @@ def main():
             rc = 1
     if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
+        if not stub:
+            dist.destroy_process_group()
     ctx.close()
+    if stub:
+        return rc, (line if rank == 0 else None)
     sys.exit(rc)
 
 

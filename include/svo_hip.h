@@ -93,6 +93,11 @@ int svo_pool_reserve(svo_ctx *ctx, uint64_t nbytes);
  * receive buffer of an RCCL broadcast owned by torch) */
 int svo_pool_upload_device(svo_ctx *ctx, const void *dptr, uint64_t nbytes);
 int svo_pool_device_ptr(svo_ctx *ctx, void **dptr, uint64_t *nbytes);
+/* the caller has finished writing the pool through svo_pool_device_ptr (e.g. an RCCL broadcast into it has completed
+ * or been enqueued): waits for the whole device, then re-reads what the library derives from the pool (dword 0 for
+ * the debug square, the beam pass's liveness table, the interior-descriptor table).  Call it before the next dispatch;
+ * a dispatch without it sees the derived data of the pool as it was when svo_pool_device_ptr was called. */
+int svo_pool_commit(svo_ctx *ctx);
 
 /* ---- world generation -------------------------------------------------------------------- */
 /* replaces Octree.constructCompleteOctree(chunkGenShader, voxelTexture, heightmapTexture, materialTexture)

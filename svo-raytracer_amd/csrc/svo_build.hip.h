@@ -324,12 +324,14 @@ __global__ void scan_add_kernel(uint32_t *out, const uint32_t *tile_offsets, uin
 __global__ void subtree_kernel(const Level lv, const uint32_t *next_sub) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= lv.count) return;
-  uint32_t s = lv.blk[i];
+  // saturating: a dense chunk's subtree sums pass 2^32 (a 60 %-filled 1024^3 noise chunk is ~4.5 GB of records), and a
+  // wrapped sum would look like a small pool to the size check -- 0xffffffff says "too large" whatever is added to it
+  uint64_t s = lv.blk[i];
   if (next_sub) {
     const uint32_t k = (uint32_t)__builtin_popcount(lv.expmask[i]), f = lv.first[i];
     for (uint32_t j = 0; j < k; j++) s += next_sub[f + j];
   }
-  lv.sub[i] = s;
+  lv.sub[i] = s > 0xffffffffull ? 0xffffffffu : (uint32_t)s;
 }
 __global__ void place_kernel(const Level lv, const uint32_t *next_sub, uint32_t *next_start) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -609,7 +611,7 @@ inline hipError_t build_levels(Builder &B, const Src &m, int n, uint64_t pad, hi
   if (B.ok()) B.err = hipStreamSynchronize(stream);
   if (!B.ok()) { B.release(); return B.err; }
   uint64_t total = pre.size();
-  for (uint32_t s : top_sub) total += s;
+  for (uint32_t s : top_sub) total += s;   // (64-bit: the saturated per-node sums cannot wrap here)
   if (total > 0x7fffffffull) {   // child pointers are signed 32-bit (Octree.java:162-168)
     B.release();
     res.len = total;

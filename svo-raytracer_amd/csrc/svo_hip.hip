@@ -282,6 +282,15 @@ int svo_pool_device_ptr(svo_ctx *c, void **dptr, uint64_t *nbytes) {
   return SVO_OK;
 }
 
+int svo_pool_commit(svo_ctx *c) {
+  if (c) { c->beam_live_valid = false; c->derived_valid = false; }
+  if (!c) return SVO_E_INVALID;
+  if (!c->d_pool) return fail(c, SVO_E_NOPOOL, "svo_pool_commit: no pool");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());   // the caller's writes (any stream) and every frame in flight
+  return refresh_dword0(c);
+}
+
 // ---------------------------------------------------------------- world generation
 __global__ void count_zero_bytes_kernel(const uint8_t *p, size_t n, unsigned int *zeros) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -604,6 +613,17 @@ static int launch_frame(svo_ctx *c, bool count) {
   const int nb = count ? 1 : c->batch;
   if (nb > 1 && !c->external_outputs)
     return fail(c, SVO_E_INVALID, "svo_set_batch: a batch renders into caller-owned outputs (svo_bind_outputs)");
+  if (nb > 1) {
+    // frame k lands frame_stride elements behind frame k - 1: the stride must cover the rows one frame writes, or the
+    // frames of the batch overwrite one another
+    int last_row = 0;
+    for (int j = f.tiles_y - 1; j >= 0; j--) {
+      const long long gy = (long long)f.y0 + (long long)j * 8 * f.row_step;
+      if (gy < (long long)std::min(f.height, f.y1)) { last_row = f.out_y0 + j * 8 + (int)std::min<long long>(8, std::min(f.height, f.y1) - gy); break; }
+    }
+    if (c->frame_stride < (uint64_t)last_row * (uint64_t)f.width)
+      return fail(c, SVO_E_INVALID, "svo_set_batch: frame_stride is smaller than the rows one frame writes");
+  }
   if (nb > 1 && f.progressive)
     return fail(c, SVO_E_INVALID, "svo_set_batch: cross-frame accumulation blends into ONE image frame after frame; "
                                   "a batch writes every frame to its own");
@@ -954,8 +974,10 @@ int svo_read_beam(svo_ctx *c, float *beam) {
   if (!c || !beam) return fail(c, SVO_E_INVALID, "svo_read_beam: null buffer");
   if (!c->beam_frames || !c->beam_cap) return fail(c, SVO_E_INVALID, "svo_read_beam: no frame was dispatched with use_beam");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   const int set = (int)((c->beam_frames - 1) % svo_ctx::kBeamSets);
+  // the frame that made this image may have run on another stream than the current one (frames in flight)
+  if (c->beam_used[set]) HIPCHK(c, hipEventSynchronize(c->beam_done[set]));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t n = (size_t)((c->width + kBeamBlock - 1) / kBeamBlock) * (size_t)((c->height + kBeamBlock - 1) / kBeamBlock);
   HIPCHK(c, hipMemcpy(beam, c->d_beam[set], std::min(n, c->beam_cap) * sizeof(float), hipMemcpyDeviceToHost));
   return SVO_OK;

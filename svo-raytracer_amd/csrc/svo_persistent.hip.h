@@ -52,11 +52,18 @@ struct PersistArgs {
   int fold;          // samples per pixel carried by this launch (see persist_launch); 1 = one launch per sample
   int group;         // fold > 1: tiles per group of a band's walk (sample by sample inside a group)
   int thresh_num;    // a round starts once active lanes <= thresh_num/16 of those active at its start
+  // reciprocals (udiv_magic) of a band's tile rows and of its tile slots per frame, for a full band and for the last one
+  uint32_t mg_rows[2], mg_tpf[2];
   // interior-descriptor table (svo_derive.hip.h); only read by the kDerived kernels
   const uint2 *desc;
   const uint2 *aux;
   uint32_t desc_count;
 };
+
+// n / d by multiply-high with m = ceil(2^32 / d) (made on the host, udiv_magic): exact while n * (m * d - 2^32) < 2^32,
+// i.e. for every n < 2^32 / d -- here n < 2^16 (tile counts) and d < 2^12
+__device__ __forceinline__ uint32_t udiv_by(uint32_t n, uint32_t d, uint32_t m) { return d <= 1u ? n : __umulhi(n, m); }
+inline uint32_t udiv_magic(uint32_t d) { return d <= 1u ? 0u : 0xffffffffu / d + 1u; }
 
 __device__ __forceinline__ uint32_t xcc_id() {
   uint32_t x;
@@ -243,6 +250,12 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
 #endif
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
+    // A lane leaves this block with a pixel to store (emit) and / or a new ray to set up (ninit); the store and the
+    // set-up run once per round, behind the refill, for all the lanes that need them together -- not once per branch
+    // (three copies of the store, two of the set-up with its three IEEE divisions, each for a handful of lanes).
+    bool emit = false, ninit = false, icone = false;
+    V3 ecol = mk(0.f, 0.f, 0.f), io = mk(0.f, 0.f, 0.f);
+    float edepth = 0.0f, its = 0.0f;
     if (status >= ST_HIT) {
       const Cast c = walk.result(t, status);
       status = ST_IDLE;
@@ -256,10 +269,11 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
         if (kMode == 4) h = make_uint4(0u, 0u, 0u, 0u);   // trace() casts nothing in modes >= 4 (svotrace.comp:643-646)
         a.hits[pix] = h;
       }
+      emit = true;
       if (kMode == 0) {
         if (segn == 0u && !c.hit) {
           const V3 s = sky_colour(d);
-          persist_emit(a, pix, smp, px, py, mk(0.0f + s.x, 0.0f + s.y, 0.0f + s.z), 0.0f);
+          ecol = mk(0.0f + s.x, 0.0f + s.y, 0.0f + s.z);
         } else {
           V3 vpos = mk(0.f, 0.f, 0.f);
           if (c.hit) { normal = c.normal; value = c.value; vpos = c.voxel_pos; }
@@ -272,26 +286,26 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             const float k = dot3(nd, normal);
             mask = mk(mask.x * k, mask.y * k, mask.z * k);
             if ((int)segn + 1 >= f.bounces) {
-              persist_emit(a, pix, smp, px, py, accum, depth);
+              ecol = accum; edepth = depth;
             } else {
               d = nd;
               seg++;
-              status = walk.init(t, vpos, nd, true);
+              emit = false; ninit = true; icone = true; io = vpos;
+              status = ST_ACTIVE;   // not idle: keeps its pixel (the set-up behind the refill gives the real status)
             }
           } else {
             const V3 sun = normalize3(mk(1.0f, 1.0f, 1.0f));
             const float diff = acos_pinned(dot3(nd, sun));
             if (diff < 0.4f) accum = mk(accum.x + mask.x * 7.0f, accum.y + mask.y * 7.0f, accum.z + mask.z * 7.0f);
             accum = mk(accum.x + mask.x * 1.0f, accum.y + mask.y * 1.0f, accum.z + mask.z * 1.0f);
-            persist_emit(a, pix, smp, px, py, accum, 0.0f);
+            ecol = accum;
           }
         }
       } else if (kMode == 1) {
-        V3 col;
-        if (c.hit) { const float g = 0.005f * (float)c.iter; col = mk(g, g, g); }
-        else if (c.capped) col = mk(0.3f, 0.3f, 0.6f);
-        else { const float g = 0.01f * (float)c.iter; col = mk(g, g, g); }
-        persist_emit(a, pix, smp, px, py, col, c.hit ? c.t : 0.0f);
+        if (c.hit) { const float g = 0.005f * (float)c.iter; ecol = mk(g, g, g); }
+        else if (c.capped) ecol = mk(0.3f, 0.3f, 0.6f);
+        else { const float g = 0.01f * (float)c.iter; ecol = mk(g, g, g); }
+        edepth = c.hit ? c.t : 0.0f;
       } else if (kMode == 2) {
         if (segn == 0u) {
           if (c.hit) {
@@ -308,9 +322,11 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             mask = mc;
             depth = c.t;
             seg = (seg & ~0xffu) | 1u;
-            status = walk.init(t, c.voxel_pos, sun2, false);
+            d = sun2;   // (the primary direction is not needed any more)
+            emit = false; ninit = true; icone = false; io = c.voxel_pos;
+            status = ST_ACTIVE;
           } else {
-            persist_emit(a, pix, smp, px, py, sky_colour(d), 0.0f);
+            ecol = sky_colour(d);
           }
         } else {
           V3 mc = mask;
@@ -320,16 +336,13 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             const float pen = (0.05f * (float)c.iter) / 100.0f;
             mc = mk(mc.x - pen, mc.y - pen, mc.z - pen);
           }
-          persist_emit(a, pix, smp, px, py, mc, depth);
+          ecol = mc; edepth = depth;
         }
       } else if (kMode == 3) {
-        if (c.hit) persist_emit(a, pix, smp, px, py, mk(c.normal.x * 0.5f + 0.5f, c.normal.y * 0.5f + 0.5f,
-                                                   c.normal.z * 0.5f + 0.5f), c.t);
-        else persist_emit(a, pix, smp, px, py, mk(0.f, 0.f, 0.f), 0.0f);
-      } else {
-        persist_emit(a, pix, smp, px, py, mk(0.f, 0.f, 0.f), 0.0f);
+        if (c.hit) { ecol = mk(c.normal.x * 0.5f + 0.5f, c.normal.y * 0.5f + 0.5f, c.normal.z * 0.5f + 0.5f); edepth = c.t; }
       }
     }
+    if (emit) persist_emit(a, pix, seg >> 8, px, py, ecol, edepth);
 
 #ifdef SVO_STAMPS
     st_shade += __builtin_readcyclecounter() - st_t0;
@@ -369,8 +382,12 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
           // ; the samples of a pixel (a.fold > 1) follow one another tile by tile: tile 0 sample 0, 1, ..., tile 1 sample 0,
           // ... -- what is in flight at any time are a few tiles' samples, whose primary rays are the same and whose
           // slots in the sample buffer are neighbours
+          // (the two divisions of every refill -- by the band's tile slots per frame and by its tile rows -- are
+          // multiply-highs by reciprocals made on the host)
           const uint32_t per_frame = band_frame * (uint32_t)a.fold;
-          const uint32_t fi = f.batch > 1 ? slot / per_frame : 0u;
+          const uint32_t tiles_pf = per_frame >> 6;   // tile slots of the band per frame
+          const int full_band = band_rows == a.rows_per_band ? 0 : 1;
+          const uint32_t fi = f.batch > 1 ? udiv_by(slot >> 6, tiles_pf, a.mg_tpf[full_band]) : 0u;
           const uint32_t q = (slot - fi * per_frame) >> 6;
           uint32_t si = 0u;
           int j = (int)q;
@@ -382,8 +399,8 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             si = r / gsize;
             j = (int)(first + r % gsize);
           }
-          int tile_x = j / band_rows;
-          const int tile_y = first_row + j % band_rows;
+          int tile_x = (int)udiv_by((uint32_t)j, (uint32_t)band_rows, a.mg_rows[full_band]);
+          const int tile_y = first_row + (j - tile_x * band_rows);
           if (a.reverse) tile_x = f.tiles_x - 1 - tile_x;   // serpentine: this frame ends where the next one starts
 #else
           const int tile = first_tile + (int)(slot >> 6);
@@ -413,8 +430,8 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
 #else
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
 #endif
-            status = walk.init(t, cam_o, d, false, beam_start(f, px, py));
-            if (kMode == 4) status = ST_MISS;   // no cast: straight to the (black) pixel
+            ninit = true; icone = false; io = cam_o; its = beam_start(f, px, py);
+            status = ST_ACTIVE;   // taken (the set-up below gives the real status)
           }
         }
         if (base + n >= band_total) {  // this band is used up: move on (work stealing)
@@ -430,6 +447,11 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
           break;
         }
       }
+    }
+    // ---------------- set up the new rays: regenerated bounce / shadow rays and refilled primaries together
+    if (ninit) {
+      status = walk.init(t, io, d, icone, its);
+      if (kMode == 4) status = ST_MISS;   // no cast: straight to the (black) pixel
     }
     if (__ballot(status != ST_IDLE) == 0ull) {
       if (bands_left > 0) continue;
@@ -618,6 +640,12 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.fold = fold;
   a.group = kFoldGroup;
   a.desc = desc; a.aux = aux; a.desc_count = desc_count;
+  {
+    const int last_rows = a.rows_per_band > 0 ? f.tiles_y % a.rows_per_band : 0;   // the one band that is not full (if any)
+    a.mg_rows[0] = udiv_magic((uint32_t)a.rows_per_band); a.mg_rows[1] = udiv_magic((uint32_t)last_rows);
+    a.mg_tpf[0] = udiv_magic((uint32_t)(a.rows_per_band * f.tiles_x * fold));
+    a.mg_tpf[1] = udiv_magic((uint32_t)(last_rows * f.tiles_x * fold));
+  }
   const long long work = (long long)f.ntiles * (f.batch > 1 ? f.batch : 1) * fold;
   const int blocks = work < (long long)b.blocks ? (int)work : b.blocks;
   // a ring of counter sets: frames may be in flight on different streams at the same time.  A frame's sample launches

@@ -106,6 +106,7 @@ class FrameRing:
         self.timing = False
         self.launch_ms = []                         # (GPU ms, frames) of every timed submission (svo_ring_query)
         self.timed_of = [False] * self.nbuf
+        self.gather_events = []                     # (start, end) events of every timed gather, on the communication stream
         import os
         self.host_wait = os.environ.get("SVO_RING_HOST_WAIT", "1") != "0"   # experiment knob
         self.dispatches = 0
@@ -155,6 +156,10 @@ class FrameRing:
         with ctxmgr:
             if done is not None:
                 self.comm_stream.wait_event(done)
+            t0 = None
+            if self.cuda and self.timing:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(self.comm_stream)
             full = self.buf[b]
             mine = full[self.rank]
             if self.rank == 0:
@@ -164,9 +169,11 @@ class FrameRing:
             else:
                 dist.gather(mine, gather_list=None, dst=0)
             if self.cuda:
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=self.timing)
                 ev.record(self.comm_stream)
                 self.gathered[b] = ev
+                if self.timing:
+                    self.gather_events.append((t0, ev))
 
     # ---- after the run ----------------------------------------------------------------------------
     def drain(self):
@@ -177,6 +184,13 @@ class FrameRing:
                 self.timed_of[b] = False
         if self.cuda:
             torch.cuda.synchronize()
+
+    def gather_ms(self):
+        """mean GPU milliseconds of a timed gather (events on the communication stream, after drain()); None without one"""
+        if not self.gather_events:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self.gather_events]
+        return round(sum(ms) / len(ms), 4)
 
     def frame_images(self, b, k=0):
         """(frameNumber, colour [H][W] int32, depth [H][W] float32[, hits [H][W][4] int32]) of frame k of buffer b in

@@ -20,7 +20,7 @@ EXPORTS = [
     "svo_output_device_ptrs", "svo_set_derived", "svo_derived_info",
     "svo_ring_create", "svo_ring_destroy", "svo_ring_submit", "svo_ring_wait", "svo_ring_query", "svo_ring_read_color",
     "svo_ring_read_depth", "svo_ring_read_hits", "svo_ring_read_pixel", "svo_ring_bind_slot", "svo_ring_device_ptrs",
-    "svo_set_reserved_cus",
+    "svo_set_reserved_cus", "svo_pool_commit",
 ]
 
 
@@ -79,6 +79,7 @@ def lib(path=None):
         L.svo_ring_create.argtypes = [vp, ci, ci, ci]
         L.svo_ring_destroy.argtypes = [vp]
         L.svo_set_reserved_cus.argtypes = [vp, ci]
+        L.svo_pool_commit.argtypes = [vp]
         L.svo_ring_submit.argtypes = [vp, ci, ci, ip]
         L.svo_ring_wait.argtypes = [vp, ci]
         L.svo_ring_query.argtypes = [vp, ci, ip, ip, ip, fp]
@@ -185,6 +186,9 @@ class HipContext:
 
     def pool_reserve(self, nbytes):
         self._chk(self._L.svo_pool_reserve(self._h, int(nbytes)))
+
+    def pool_commit(self):
+        self._chk(self._L.svo_pool_commit(self._h))
 
     def pool_device_ptr(self):
         p, n = ctypes.c_void_p(), ctypes.c_uint64()

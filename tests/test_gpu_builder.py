@@ -126,6 +126,27 @@ def test_builder_rejects_bad_input(ctx):
         ctx.build_from_heightmap(h, m)            # material 0 = the empty voxel
 
 
+def test_builder_reports_too_large_and_keeps_the_pool(ctx):
+    """A dense random chunk is gigabytes of records (child pointers are signed 32-bit, Octree.java:162-168): 1024^3 of 60 %
+    noise is ~4.5 GB, which wraps a 32-bit byte sum back into range -- the builder must say SVO_E_TOOLARGE (-5), write
+    nothing out of bounds, and leave the context's previous pool in place."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    small, _ = scene.build_scene(64)
+    ctx.set_pipeline(1)
+    before = ctx.render(small, 96, 64, CAMERAS["K1"], 2, 0)
+    rng = np.random.default_rng(7)
+    grid = (rng.integers(0, 5, size=(1024, 1024, 1024), dtype=np.uint8) < 3).astype(np.uint8)   # 60 % solid
+    with pytest.raises(hiplib.SvoError) as e:
+        ctx.build_from_voxels(grid)
+    assert e.value.code == -5
+    del grid
+    assert (ctx.pool_download(small.size) == small).all()
+    after = ctx.render(None, 96, 64, CAMERAS["K1"], 2, 0)
+    assert (after["rgba"] == before["rgba"]).all() and after["hits"].tobytes() == before["hits"].tobytes()
+
+
 # ---- dense voxel chunks: Octree.constructInnerOctree's own input ----------------------------------------------------
 
 def _restated_from_grid(grid):

@@ -146,3 +146,52 @@ def test_ring_with_caller_owned_slots_and_stripes(ctx):
     assert ctx.ring_device_ptrs(0)["frame_stride"] == w * h
     ctx.ring_destroy()
     ctx.resize(w + 8, h)   # resets the stripes
+
+
+def test_batch_stride_must_cover_a_frame(ctx):
+    import torch
+    from svo_raytracer_amd.hiplib import SvoError
+    w, h = 128, 80
+    ctx.set_pipeline(1)
+    ctx.resize(w, h)
+    buf = torch.zeros((2, 3, h, w), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.bind_outputs(buf[0].data_ptr(), buf[1].data_ptr(), None)
+    ctx.set_params(2, 0)
+    ctx.set_batch(3, w * h - 1)          # one element short: frames would overlap
+    with pytest.raises(SvoError):
+        ctx.dispatch()
+    ctx.set_batch(3, w * h)
+    ctx.dispatch()
+    ctx.set_batch(1, 0)
+    ctx.bind_outputs(None, None, None)
+
+
+def test_pool_written_through_the_device_pointer_needs_commit(ctx):
+    """svo_pool_reserve + svo_pool_device_ptr + (the caller's copy, e.g. an RCCL broadcast) + svo_pool_commit"""
+    import ctypes
+    import torch
+    import svo_raytracer_amd.scene as scene
+    from oracle import oracle
+    from svo_raytracer_amd.cameras import CAMERAS
+    a, _ = scene.build_scene(128)
+    b, _ = scene.build_scene(64)
+    w, h = 96, 64
+    for pipeline in (0, 1):
+        ctx.set_pipeline(pipeline)
+        ctx.render(a, w, h, CAMERAS["K1"], 2, 0)           # the context holds pool a (and its derived tables)
+        ctx.pool_reserve(b.size)
+        ptr, n = ctx.pool_device_ptr()
+        assert n == b.size
+        src = torch.from_numpy(b).cuda()
+        torch.cuda.synchronize()
+        # the caller's own asynchronous copy into the library's pool, on torch's stream, as a broadcast would be
+        hip = ctypes.CDLL("libamdhip64.so.7")   # the soname torch's runtime is already mapped under: the same library, not a second one
+        hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        assert hip.hipMemcpyAsync(ctypes.c_void_p(ptr), ctypes.c_void_p(src.data_ptr()), b.size, 3,
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        ctx.pool_commit()
+        got = ctx.render(None, w, h, CAMERAS["K1"], 2, 0)
+        ref = oracle.render(b, w, h, CAMERAS["K1"], 2, 0)
+        assert (got["rgba"] == ref["rgba"]).all() and (got["hits"]["pointer"] == ref["hits"]["pointer"]).all()
+    ctx.pool_upload(scene.build_scene(256)[0])              # what the module's other tests expect
