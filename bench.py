@@ -101,6 +101,9 @@ def parse(argv=None):
     ap.add_argument("--beam", type=int, default=0, help="useBeamOptimization (coarse depth pre-pass, Main.java:257-266)")
     ap.add_argument("--comm-cus", type=int, default=-1, help="CUs per XCD the render streams leave free for the collective's kernels "
                                                               "(svo_set_reserved_cus); -1 = 1 when ranks exchange tiles, else 0")
+    ap.add_argument("--exchange", choices=["rccl", "copy"], default=os.environ.get("SVO_BENCH_EXCHANGE", "rccl"),
+                    help="how a rank's tiles reach rank 0: one RCCL gather per dispatch (default), or device-to-device copies into "
+                         "rank 0's buffer through its IPC handle (svo_ring_forward_slot: SDMA, no CU slots needed)")
     ap.add_argument("--as-rank", default=None, help="r/n: render what rank r of n would, on one GPU, no communication")
     args = ap.parse_args(argv)
     preset = PRESETS[args.config or "C3"]
@@ -231,15 +234,19 @@ def main(argv=None, ctx_factory=None):
         if not stub:
             torch.cuda.synchronize()
 
+    # SVO_BENCH_ONE_GPU=1 (tests): every rank on GPU 0 -- RCCL refuses that, the copy exchange (IPC) and gloo do not
+    one_gpu = os.environ.get("SVO_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     if not stub:
         torch.cuda.set_device(local_rank)
     force_comm = os.environ.get("SVO_BENCH_FORCE_COMM", "0") == "1"  # exercise the RCCL path on one GPU
     if (world > 1 or (force_comm and "RANK" in os.environ)) and not dist.is_initialized():
-        if stub:
+        if stub or os.environ.get("SVO_BENCH_BACKEND", "") == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    use_comm = world > 1 or (force_comm and dist.is_initialized())
+    use_comm = (world > 1 and args.exchange == "rccl") or (force_comm and dist.is_initialized())
 
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
@@ -278,7 +285,7 @@ def main(argv=None, ctx_factory=None):
     ctx.resize(W, H_total)
     ctx.set_camera(cam)
     ctx.set_pipeline(args.pipeline)
-    nbuf = min(8, max(2 if use_comm else 1, args.inflight))
+    nbuf = min(8, max(2 if (use_comm or world > 1) else 1, args.inflight))
     batch = args.batch if args.batch > 0 else default_batch(args, world if as_rank is None else as_rank[1])
     waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
     if args.pipeline == 1:
@@ -290,8 +297,8 @@ def main(argv=None, ctx_factory=None):
     params = dict(render_mode=args.mode, buffer_end=nbytes, use_beam=args.beam, bounces=args.bounces,
                   mirror_mask=args.mirror, spp=args.spp)
     ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device=dev,
-                     dist=dist if use_comm else None, want_hits=bool(args.hits), force_comm=force_comm,
-                     first_frame=2, params=params, as_rank=as_rank, batch=batch)
+                     dist=dist if (use_comm or world > 1) else None, want_hits=bool(args.hits), force_comm=force_comm,
+                     first_frame=2, params=params, as_rank=as_rank, batch=batch, exchange=args.exchange)
 
     # ---- ray count (untimed counting pass of the first and the last timed frame) ---------------------
     def count(frame):    # on the context's own stream and images (the ring's slots are not involved)
@@ -432,7 +439,7 @@ def main(argv=None, ctx_factory=None):
             "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
             "gather_ms": ring.gather_ms(),
-            "comm_cus_per_xcd": comm_cus,
+            "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if world > 1 else None),
             "config": {
                 "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %d spp, camera %s, "
                             "frameNumber %d..%d (one per step), pipeline %d, %s" % (

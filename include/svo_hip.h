@@ -239,6 +239,24 @@ int svo_ring_bind_slot(svo_ctx *ctx, int slot, void *color, void *depth, void *h
  * collective that reads the slot behind its frames).  Any may be NULL. */
 int svo_ring_device_ptrs(svo_ctx *ctx, int slot, void **color, void **depth, void **hits, uint64_t *frame_stride, void **stream);
 
+/* The tile exchange without a collective's kernels (one process per GPU): a rank's slot may forward what it
+ * rendered straight into the frame owner's memory.  After every svo_ring_submit into `slot` the library enqueues, on the
+ * slot's stream behind the launch, a device-to-device copy of nbytes from src (this rank's chunk, e.g. what
+ * svo_ring_bind_slot bound) to dst (the owner's gather buffer at this rank's chunk, opened with svo_ipc_open), then the
+ * number of the submission (1, 2, ... over the ring's lifetime) into the 32-bit word *flag (owner's memory as well,
+ * NULL = none): the owner knows a rank's frames have landed when the word has reached the submission it waits for.
+ * Between GPUs such copies run on the SDMA engines: they need no CU slot next to the persistent waves, which an RCCL
+ * send / receive does.  dst == NULL switches forwarding off. */
+int svo_ring_forward_slot(svo_ctx *ctx, int slot, const void *src, void *dst, uint64_t nbytes, void *flag);
+/* device memory that can be shared with the other ranks of the node: plain allocations (zeroed), their 64-byte IPC
+ * handles, and a peer's allocation opened from its handle (hipIpcGetMemHandle / hipIpcOpenMemHandle) */
+int svo_dev_alloc(svo_ctx *ctx, uint64_t nbytes, void **dptr);
+int svo_dev_free(svo_ctx *ctx, void *dptr);
+int svo_dev_read(svo_ctx *ctx, const void *dptr, void *host, uint64_t nbytes);
+int svo_ipc_export(svo_ctx *ctx, void *dptr, void *handle64);
+int svo_ipc_open(svo_ctx *ctx, const void *handle64, void **dptr);
+int svo_ipc_close(svo_ctx *ctx, void *dptr);
+
 /* ---- readback ------------------------------------------------------------------- */
 /* replaces glGetTexImage of image 0 (rgba8; row 0 = p.y = 0, bytes R,G,B,A) and
  * image 1 (r32f depth) (Main.java:132-146, svotrace.comp:726-727) */

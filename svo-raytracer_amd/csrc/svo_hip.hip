@@ -76,7 +76,11 @@ struct svo_ctx {
     void *xcolor = nullptr, *xdepth = nullptr, *xhits = nullptr; uint64_t xstride = 0;   // caller-owned (svo_ring_bind_slot)
     int first_frame = 0, nframes = 0;
     bool used = false;
+    // svo_ring_forward_slot: after every submission, src -> dst (a peer's memory) and the submission's number -> *fwd_flag
+    const void *fwd_src = nullptr; void *fwd_dst = nullptr; uint64_t fwd_bytes = 0; void *fwd_flag = nullptr;
+    uint32_t *seq_word = nullptr;
   };
+  std::vector<void *> ipc_opened;
   std::vector<RingSlot> ring;
   int reserved_cus = 0;        // CUs per XCD the ring's streams leave free (svo_set_reserved_cus)
   int ring_frames = 0;
@@ -131,6 +135,7 @@ static void ring_free(svo_ctx *c) {
     if (s.hits) (void)hipFree(s.hits);
     if (s.e0) (void)hipEventDestroy(s.e0);
     if (s.e1) (void)hipEventDestroy(s.e1);
+    if (s.seq_word) (void)hipFree(s.seq_word);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   c->ring.clear();
@@ -168,6 +173,7 @@ int svo_destroy(svo_ctx *c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   ring_free(c);
+  for (void *p : c->ipc_opened) if (p) (void)hipIpcCloseMemHandle(p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return SVO_OK;
@@ -844,6 +850,15 @@ int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
   hipError_t e = hipEventRecord(s.e0, s.stream);
   if (e == hipSuccess) rc = launch_frame(c, false);
   if (e == hipSuccess && rc == SVO_OK) e = hipEventRecord(s.e1, s.stream);
+  if (e == hipSuccess && rc == SVO_OK && s.fwd_dst) {
+    // the slot's frames travel to the frame owner behind the launch, on the same stream: a device-to-device copy (SDMA
+    // between GPUs: no CU slot needed next to the persistent waves), then the submission's number into the owner's flag
+    e = hipMemcpyAsync(s.fwd_dst, s.fwd_src, s.fwd_bytes, hipMemcpyDeviceToDevice, s.stream);
+    if (e == hipSuccess && s.fwd_flag) {
+      e = hipMemsetD32Async((hipDeviceptr_t)s.seq_word, (int)(c->ring_next + 1u), 1, s.stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(s.fwd_flag, s.seq_word, 4, hipMemcpyDeviceToDevice, s.stream);
+    }
+  }
   c->stream = sv.stream; c->d_color = sv.col; c->d_depth = sv.dep; c->d_hits = sv.hit; c->external_outputs = sv.ext;
   c->batch = sv.batch; c->frame_stride = sv.stride; c->frame_number = sv.frame;
   if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_ring_submit: ") + hipGetErrorString(e));
@@ -944,6 +959,65 @@ int svo_ring_read_pixel(svo_ctx *c, int slot, int k, int x, int y, void *rgba8, 
     HIPCHK(c, hipMemcpy(hit, hp + o, 16, hipMemcpyDeviceToHost));
   }
   return SVO_OK;
+}
+
+int svo_ring_forward_slot(svo_ctx *c, int slot, const void *src, void *dst, uint64_t nbytes, void *flag) {
+  svo_ctx::RingSlot *s = ring_slot(c, slot, "svo_ring_forward_slot");
+  if (!s) return SVO_E_INVALID;
+  if (dst && (!src || nbytes == 0)) return fail(c, SVO_E_INVALID, "svo_ring_forward_slot: source and size required");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (dst && !s->seq_word) HIPCHK(c, hipMalloc((void **)&s->seq_word, 4));
+  s->fwd_src = dst ? src : nullptr; s->fwd_dst = dst; s->fwd_bytes = dst ? nbytes : 0; s->fwd_flag = dst ? flag : nullptr;
+  return SVO_OK;
+}
+
+// ---------------------------------------------------------------- device memory shared between the ranks of one node
+int svo_dev_alloc(svo_ctx *c, uint64_t nbytes, void **dptr) {
+  if (!c || !dptr || nbytes == 0) return fail(c, SVO_E_INVALID, "svo_dev_alloc: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMalloc(dptr, nbytes));
+  HIPCHK(c, hipMemset(*dptr, 0, nbytes));
+  HIPCHK(c, hipDeviceSynchronize());
+  return SVO_OK;
+}
+int svo_dev_free(svo_ctx *c, void *dptr) {
+  if (!c) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  if (dptr) HIPCHK(c, hipFree(dptr));
+  return SVO_OK;
+}
+int svo_dev_read(svo_ctx *c, const void *dptr, void *host, uint64_t nbytes) {
+  if (!c || !dptr || !host) return fail(c, SVO_E_INVALID, "svo_dev_read: null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(host, dptr, nbytes, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+int svo_ipc_export(svo_ctx *c, void *dptr, void *handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  if (!c || !dptr || !handle64) return fail(c, SVO_E_INVALID, "svo_ipc_export: null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipIpcMemHandle_t h;
+  HIPCHK(c, hipIpcGetMemHandle(&h, dptr));
+  memcpy(handle64, &h, sizeof h);
+  return SVO_OK;
+}
+int svo_ipc_open(svo_ctx *c, const void *handle64, void **dptr) {
+  if (!c || !dptr || !handle64) return fail(c, SVO_E_INVALID, "svo_ipc_open: null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof h);
+  HIPCHK(c, hipIpcOpenMemHandle(dptr, h, hipIpcMemLazyEnablePeerAccess));
+  c->ipc_opened.push_back(*dptr);
+  return SVO_OK;
+}
+int svo_ipc_close(svo_ctx *c, void *dptr) {
+  if (!c || !dptr) return SVO_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  for (auto &p : c->ipc_opened)
+    if (p == dptr) { p = nullptr; HIPCHK(c, hipIpcCloseMemHandle(dptr)); return SVO_OK; }
+  return fail(c, SVO_E_INVALID, "svo_ipc_close: not opened by this context");
 }
 
 int svo_ring_device_ptrs(svo_ctx *c, int slot, void **color, void **depth, void **hits, uint64_t *frame_stride, void **stream) {

@@ -45,9 +45,13 @@ class _NoStream:
 
 class FrameRing:
     def __init__(self, renderer, width, height, world=1, rank=0, nbuf=3, device="cuda", dist=None,
-                 want_hits=False, force_comm=False, first_frame=2, params=None, as_rank=None, batch=1):
+                 want_hits=False, force_comm=False, first_frame=2, params=None, as_rank=None, batch=1, exchange="rccl"):
         """params: dict(render_mode, buffer_end, use_beam, bounces, mirror_mask, spp) -- constant over the run.
-        as_rank = (r, n): render what rank r of n would, without any communication (single-GPU what-if runs)."""
+        as_rank = (r, n): render what rank r of n would, without any communication (single-GPU what-if runs).
+        exchange: how a rank's chunk reaches the frame owner -- "rccl": one gather per dispatch on a communication stream
+        (send / receive kernels, which need CU slots next to the persistent waves); "copy": the library forwards every
+        slot into the owner's gather buffer (opened through its IPC handle) with a device-to-device copy behind the launch,
+        and a sequence word per rank tells the owner when it has landed (svo_ring_forward_slot; SDMA between GPUs)."""
         self.r = renderer
         self.W, self.H = int(width), int(height)
         self.world, self.rank = int(world), int(rank)
@@ -55,7 +59,9 @@ class FrameRing:
         self.dist = dist
         self.cuda = torch.device(device).type == "cuda"
         self.device = device
-        self.use_comm = dist is not None and (self.world > 1 or force_comm)
+        self.exchange = exchange if (dist is not None and self.world > 1) else "rccl"
+        self.copy_mode = self.exchange == "copy"
+        self.use_comm = dist is not None and (self.world > 1 or force_comm) and not self.copy_mode
         self.force_comm = force_comm
         self.planes = 2 + (4 if want_hits else 0)
         self.want_hits = want_hits
@@ -78,7 +84,10 @@ class FrameRing:
         # torch-owned gather buffers, [world][planes][batch][rpr][W] words; rank r's chunk is self.buf[b][r].  Not needed
         # (library-owned images instead) when this process renders whole frames for itself.
         self.own_images = (not self.use_comm) and as_rank is None and self.world == 1
-        self.buf = None if self.own_images else [
+        self.gbuf, self.remote = None, None
+        if self.copy_mode:
+            self._setup_copy_exchange(rpr)
+        self.buf = None if (self.own_images or (self.copy_mode and self.rank == 0)) else [
             torch.zeros((self.chunk_world, self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
             for _ in range(self.nbuf)]
         self.frame_of = [None] * self.nbuf          # first frameNumber held by each slot
@@ -88,10 +97,19 @@ class FrameRing:
         self.my_chunk = self.rank if as_rank is None else 0
         if self.cuda:
             torch.cuda.synchronize()                # the buffers are zeroed before a slot's stream writes them
-        if self.buf is not None:
+        if self.copy_mode and self.rank != 0:
+            self.chunk_world, self.my_chunk = 1, 0       # only this rank's chunk lives here; it travels by copy
+            self.buf = [torch.zeros((1, self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
+                        for _ in range(self.nbuf)]
+            if self.cuda:
+                torch.cuda.synchronize()
+        if self.buf is not None or self.copy_mode:
             for b in range(self.nbuf):
                 c, d, h = self._ptrs(b)
                 self.r.ring_bind_slot(b, c, d, h, rpr * self.W)
+                if self.copy_mode and self.rank != 0:
+                    cb = self.chunk_bytes
+                    self.r.ring_forward_slot(b, c, self.remote[b] + self.rank * cb, cb, self.remote[b] + self.world * cb + 4 * self.rank)
         if self.cuda and self.use_comm:
             # the slots' streams, wrapped so that torch events can order the gather against them.  HIP maps streams onto
             # a small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default): two frame streams on one queue
@@ -103,6 +121,7 @@ class FrameRing:
             self.streams = [_NoStream() for _ in range(self.nbuf)]
             self.comm_stream = _NoStream() if self.use_comm else None
         self.gathered = [None] * self.nbuf          # event: the gather that last read buffer b has finished
+        self.last_seq = [0] * self.nbuf             # number (1, 2, ...) of the last dispatch into buffer b
         self.timing = False
         self.launch_ms = []                         # (GPU ms, frames) of every timed submission (svo_ring_query)
         self.timed_of = [False] * self.nbuf
@@ -111,11 +130,42 @@ class FrameRing:
         self.host_wait = os.environ.get("SVO_RING_HOST_WAIT", "1") != "0"   # experiment knob
         self.dispatches = 0
 
+    def _setup_copy_exchange(self, rpr):
+        """rank 0 owns one gather buffer per slot, [world chunks][world sequence words], allocated by the library (a
+        whole allocation, so that its IPC handle maps it from its first byte) and opened by every other rank"""
+        self.chunk_bytes = self.planes * self.batch * rpr * self.W * 4
+        total = self.world * self.chunk_bytes + 4 * self.world
+        handles = [None] * self.nbuf
+        if self.rank == 0:
+            self.gbuf = [self.r.dev_alloc(total) for _ in range(self.nbuf)]
+            handles = [self.r.ipc_export(p) for p in self.gbuf]
+        self.dist.broadcast_object_list(handles, src=0)
+        if self.rank != 0:
+            self.remote = [self.r.ipc_open(h) for h in handles]
+
+    def landed(self, b, timeout_s=20.0):
+        """frame owner, copy exchange: wait until every rank's chunk of the last dispatch into buffer b has arrived"""
+        import time
+        import numpy as np
+        if not (self.copy_mode and self.rank == 0) or self.last_seq[b] == 0:
+            return True
+        t0 = time.time()
+        while True:
+            flags = self.r.dev_read(self.gbuf[b] + self.world * self.chunk_bytes, 4 * self.world, dtype=np.uint32)
+            if all(int(flags[r]) >= self.last_seq[b] for r in range(1, self.world)):
+                return True
+            if time.time() - t0 > timeout_s:
+                raise RuntimeError("copy exchange: buffer %d still waits for ranks %s (sequence %d, flags %s)" % (
+                    b, [r for r in range(1, self.world) if int(flags[r]) < self.last_seq[b]], self.last_seq[b], flags.tolist()))
+            time.sleep(0.0005)
+
     # ---- one frame ------------------------------------------------------------------------------
     def _ptrs(self, b):
-        mine = self.buf[b][self.my_chunk]
         word = 4
-        base = mine.data_ptr()
+        if self.copy_mode and self.rank == 0:
+            base = self.gbuf[b]                       # the owner renders its chunk (chunk 0) in place
+        else:
+            base = self.buf[b][self.my_chunk].data_ptr()
         plane = self.batch * self.rows_per_rank * self.W * word
         return base, base + plane, (base + 2 * plane if self.want_hits else None)
 
@@ -136,6 +186,7 @@ class FrameRing:
             self.streams[b].wait_event(self.gathered[b])
         slot = self.r.ring_submit(frame, n)
         assert slot == b, (slot, b)
+        self.last_seq[b] = self.dispatches
         self.frame_of[b] = frame
         self.count_of[b] = n
         self.timed_of[b] = self.timing
@@ -184,6 +235,8 @@ class FrameRing:
                 self.timed_of[b] = False
         if self.cuda:
             torch.cuda.synchronize()
+        for b in range(self.nbuf):
+            self.landed(b)
 
     def gather_ms(self):
         """mean GPU milliseconds of a timed gather (events on the communication stream, after drain()); None without one"""
@@ -202,7 +255,14 @@ class FrameRing:
             if self.want_hits:
                 out = out + (torch.from_numpy(img["hits"].view("<i4").reshape(self.H, self.W, 4)),)
             return out
-        full = self.buf[b][:, :, k]             # [chunks][planes][rpr][W]
+        if self.copy_mode and self.rank == 0:   # the gather buffer is the library's: read it back, then as below
+            import numpy as np
+            self.landed(b)
+            raw = self.r.dev_read(self.gbuf[b], self.world * self.chunk_bytes, dtype=np.int32)
+            whole = torch.from_numpy(raw.reshape(self.world, self.planes, self.batch, self.rows_per_rank, self.W).copy())
+        else:
+            whole = self.buf[b]
+        full = whole[:, :, k]                   # [chunks][planes][rpr][W]
         per = self.rows_per_rank // TILE
         cw = full.shape[0]
         lw = self.layout_world
@@ -222,7 +282,7 @@ class FrameRing:
         depth = order(full[:, 1]).view(torch.float32)
         if self.want_hits:
             # the hit image is pixel-major (16 bytes per pixel) inside the chunk's last four plane-sized slots
-            hits = order(self.buf[b][:, 2:6].reshape(cw, self.batch, self.rows_per_rank, self.W, 4)[:, k])
+            hits = order(whole[:, 2:6].reshape(cw, self.batch, self.rows_per_rank, self.W, 4)[:, k])
             return self.frame_of[b] + k, color, depth, hits
         return self.frame_of[b] + k, color, depth
 

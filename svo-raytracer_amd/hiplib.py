@@ -20,7 +20,8 @@ EXPORTS = [
     "svo_output_device_ptrs", "svo_set_derived", "svo_derived_info",
     "svo_ring_create", "svo_ring_destroy", "svo_ring_submit", "svo_ring_wait", "svo_ring_query", "svo_ring_read_color",
     "svo_ring_read_depth", "svo_ring_read_hits", "svo_ring_read_pixel", "svo_ring_bind_slot", "svo_ring_device_ptrs",
-    "svo_set_reserved_cus", "svo_pool_commit",
+    "svo_set_reserved_cus", "svo_pool_commit", "svo_ring_forward_slot", "svo_dev_alloc", "svo_dev_free", "svo_dev_read",
+    "svo_ipc_export", "svo_ipc_open", "svo_ipc_close",
 ]
 
 
@@ -80,6 +81,13 @@ def lib(path=None):
         L.svo_ring_destroy.argtypes = [vp]
         L.svo_set_reserved_cus.argtypes = [vp, ci]
         L.svo_pool_commit.argtypes = [vp]
+        L.svo_ring_forward_slot.argtypes = [vp, ci, vp, vp, u64, vp]
+        L.svo_dev_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
+        L.svo_dev_free.argtypes = [vp, vp]
+        L.svo_dev_read.argtypes = [vp, vp, vp, u64]
+        L.svo_ipc_export.argtypes = [vp, vp, vp]
+        L.svo_ipc_open.argtypes = [vp, vp, ctypes.POINTER(vp)]
+        L.svo_ipc_close.argtypes = [vp, vp]
         L.svo_ring_submit.argtypes = [vp, ci, ci, ip]
         L.svo_ring_wait.argtypes = [vp, ci]
         L.svo_ring_query.argtypes = [vp, ci, ip, ip, ip, fp]
@@ -288,6 +296,38 @@ class HipContext:
     def ring_bind_slot(self, slot, color_ptr, depth_ptr, hits_ptr, frame_stride):
         self._chk(self._L.svo_ring_bind_slot(self._h, int(slot), ctypes.c_void_p(color_ptr or 0), ctypes.c_void_p(depth_ptr or 0),
                                              ctypes.c_void_p(hits_ptr or 0), int(frame_stride)))
+
+    def ring_forward_slot(self, slot, src, dst, nbytes, flag=None):
+        self._chk(self._L.svo_ring_forward_slot(self._h, int(slot), ctypes.c_void_p(src or 0), ctypes.c_void_p(dst or 0), int(nbytes),
+                                                ctypes.c_void_p(flag or 0)))
+
+    # device memory shared between the ranks of a node
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._chk(self._L.svo_dev_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        self._chk(self._L.svo_dev_free(self._h, ctypes.c_void_p(ptr)))
+
+    def dev_read(self, ptr, nbytes, dtype=np.uint8):
+        out = np.zeros(int(nbytes), dtype=np.uint8)
+        self._chk(self._L.svo_dev_read(self._h, ctypes.c_void_p(ptr), out.ctypes.data, out.size))
+        return out.view(dtype)
+
+    def ipc_export(self, ptr):
+        h = (ctypes.c_uint8 * 64)()
+        self._chk(self._L.svo_ipc_export(self._h, ctypes.c_void_p(ptr), h))
+        return bytes(h)
+
+    def ipc_open(self, handle):
+        buf = (ctypes.c_uint8 * 64).from_buffer_copy(handle)
+        p = ctypes.c_void_p()
+        self._chk(self._L.svo_ipc_open(self._h, buf, ctypes.byref(p)))
+        return p.value
+
+    def ipc_close(self, ptr):
+        self._chk(self._L.svo_ipc_close(self._h, ctypes.c_void_p(ptr)))
 
     def ring_device_ptrs(self, slot):
         a, b, c, st = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()

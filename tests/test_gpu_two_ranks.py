@@ -1,0 +1,112 @@
+"""More than one rank on the GPU box: the box has ONE MI355X and RCCL refuses two ranks on one device, but the copy
+exchange (svo_ring_forward_slot: device-to-device copies into the frame owner's buffer through its IPC handle) and gloo
+(control messages only) do not.  Two and three processes, each with its own HipContext on GPU 0: pool replication,
+stripe split, forwarding with sequence words, reassembly on rank 0 -- the whole N > 1 data path on real hardware except
+the xGMI hop itself -- against the oracle; then bench.py itself run that way."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, nbuf, batch, steps, want_hits, out_path):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    from svo_raytracer_amd.framering import FrameRing, replicate_pool
+    pool = scene.build_scene(128)[0] if rank == 0 else None
+    dpool = replicate_pool(dist, pool, rank, world, device="cpu")
+    ctx = hiplib.HipContext(0)
+    ctx.pool_upload(dpool.numpy())
+    ctx.resize(w, h)
+    ctx.set_camera(CAMERAS["K1"])
+    ctx.set_pipeline(1)
+    ctx.set_tuning(6, 9)
+    ring = FrameRing(ctx, w, h, world=world, rank=rank, nbuf=nbuf, device="cuda", dist=dist, want_hits=want_hits,
+                     first_frame=2, params=dict(render_mode=0, buffer_end=int(dpool.numel())), batch=batch, exchange="copy")
+    left = steps
+    while left > 0:
+        n = min(batch, left)
+        ring.step(n)
+        left -= n
+    torch.cuda.synchronize()
+    dist.barrier()          # every rank's copies have been enqueued and completed on its streams
+    ring.drain()
+    if rank == 0:
+        out, i = {}, 0
+        for b in range(nbuf):
+            for k in range(ring.count_of[b]):
+                imgs = ring.frame_images(b, k)
+                out["frame%d" % i] = np.int64(imgs[0])
+                out["color%d" % i] = imgs[1].numpy()
+                out["depth%d" % i] = imgs[2].numpy()
+                if want_hits:
+                    out["hits%d" % i] = imgs[3].numpy()
+                i += 1
+        out["nframes"] = np.int64(i)
+        np.savez(out_path, **out)
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nbuf,batch,steps,want_hits", [(2, 2, 1, 5, False), (2, 3, 2, 9, True), (3, 2, 3, 8, False)])
+def test_copy_exchange_between_ranks_on_one_gpu(tmp_path, world, nbuf, batch, steps, want_hits):
+    import svo_raytracer_amd.scene as scene
+    from oracle import oracle
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    w, h = 200, 120
+    out = str(tmp_path / "frames.npz")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, nbuf, batch, steps, want_hits, out), nprocs=world, join=True)
+    z = np.load(out)
+    pool = scene.build_scene(128)[0]
+    assert int(z["nframes"]) >= 1
+    seen = set()
+    for i in range(int(z["nframes"])):
+        fr = int(z["frame%d" % i])
+        seen.add(fr)
+        ref = oracle.render(pool, w, h, CAMERAS["K1"], fr, 0, want_hits=want_hits)
+        assert (z["color%d" % i].view(np.uint8).reshape(h, w, 4) == ref["rgba"]).all(), fr
+        assert (z["depth%d" % i].view(np.uint32) == ref["depth"].view(np.uint32)).all(), fr
+        if want_hits:
+            assert z["hits%d" % i].astype(np.int32).tobytes() == ref["hits"].view(np.int32).reshape(h, w, 4).tobytes(), fr
+    assert max(seen) == 2 + steps - 1       # the last frame dispatched is among those the ring still holds
+
+
+def test_bench_two_ranks_on_one_gpu_copy_exchange():
+    """bench.py --gpus 2 --exchange copy with both ranks on GPU 0 (gloo for the control plane): verified line"""
+    env = dict(os.environ, SVO_BENCH_BACKEND="gloo", SVO_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "copy", "--size", "512",
+           "--width", "640", "--height", "360", "--steps", "12", "--warmup", "4", "--inflight", "2", "--batch", "2", "--waves", "6",
+           "--cpu-seconds", "0", "--isolated", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["verified"] is True and line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["exchange"] == "copy"
+    assert line["value"] > 0
