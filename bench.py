@@ -22,9 +22,9 @@ depth in one message) are gathered to rank 0 over xGMI (one direct send per peer
 the next frames' traversal.  --scaling weak keeps 1920x1080 pixels per GPU instead (the frame grows
 to 1920 x 1080*N rows of the same view).
 
-Throughput configuration (all of it on the JSON line): --inflight 4 dispatches in flight on alternating streams, each
-dispatch a batch of --batch 5 consecutive frames (svo_set_batch: one persistent launch whose waves run from frame to
-frame, so the launch's tail is paid once per batch).  A step is still ONE frame: K steps = K frames, the last dispatch
+Throughput configuration (all of it on the JSON line, and all of it behind the C ABI: svo_ring_*): --inflight 6 submissions in
+flight, each in a ring slot with a stream of its own, each a batch of --batch 4 consecutive frames (one persistent launch
+whose waves run from frame to frame, so the launch's tail is paid once per batch).  A step is still ONE frame: K steps = K frames, the last dispatch
 a partial batch if need be.  `--inflight 1 --batch 1` is the reference's own loop, one frame at a time.
 
 Presets: --config C2 | C3 (default, the metric) | C4 | C5 are BASELINE.json's configs.
@@ -51,13 +51,13 @@ CLOCK_HZ = 2.4e9
 VALU_CYCLES = 2.5       # measured: a SIMD retires one wave64 VALU instruction per ~2.5 cycles (profiles/r01b_calib_valu.txt)
 
 # frames per dispatch when --batch is not given (the same for every number of GPUs, so that the scaling curve compares like
-# with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N
-# (tools/history/r02_batch_probe.sh, tools/history/r02_batch.sh: 1 GPU 4.38 -> 4.54 Grays/s; rank 0 of 8: 0.152 -> 0.106 ms per frame).
-# 4 dispatches in flight x 5 frames instead of 3 x 4 (tools/history/r03_shortrun*.sh): the same in a long run (4.58 against 4.53
-# Grays/s at 400 steps) and much less lost to the start and the drain of a short timed region -- 20 steps: 4.43 against
-# 4.13, 40 steps: 4.50 against 4.14 (20 steps = four dispatches that start together and end together)
-DEFAULT_BATCH = {1: 5, 2: 5, 4: 5, 8: 5}
-DEFAULT_INFLIGHT = 4
+# with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N.
+# 6 dispatches in flight x 4 frames (tools/r04_shape*.sh, profiles/round3_experiments.txt): in a long run every shape from
+# 4 x 5 to 8 x 4 is within 1.5 % (5.35-5.45 Grays/s at 200 steps); a short timed region -- a driver's `--steps 20 --warmup 5`
+# -- is all start and drain, and there 6 x 4 (5.15 at 20 steps, 5.16 at 40) beats round 2's 4 x 5 (4.83, 4.99) because the
+# whole region is submitted at once and ends in ONE tail.
+DEFAULT_BATCH = {1: 4, 2: 4, 4: 4, 8: 4}
+DEFAULT_INFLIGHT = 6
 
 PRESETS = {
     # name: size, width, height, mode, bounces (path segments), mirror mask, spp
@@ -176,7 +176,7 @@ def default_batch(args, world):
     (the library folds them into it), so such frames go one per dispatch."""
     if args.spp > 1:
         return 1
-    return DEFAULT_BATCH.get(world, 5 if world > 8 else 1)
+    return DEFAULT_BATCH.get(world, 4 if world > 8 else 1)
 
 
 def pmc_key(args, width, height, nbuf, batch):

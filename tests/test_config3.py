@@ -155,8 +155,8 @@ def test_config3_as_the_benchmark_runs_it(pool8192):
 @pytest.mark.gpu
 def test_config3_through_the_jni_ring(pool8192):
     """The same throughput configuration behind the drop-in boundary: JNI-typed calls only (what HipRenderer.java's
-    createFrameRing / submitFrames / readFrame make) -- a library-owned ring of 4 slots x 5 frames, four submissions in
-    flight, the golden frames 2 and 57 read back out of their slots; no torch stream or tensor involved."""
+    createFrameRing / submitFrames / readFrame make) -- a library-owned ring of 6 slots x 4 frames, six submissions in
+    flight (bench.py's default shape), the golden frames 2 and 57 read back out of their slots; no torch stream or tensor involved."""
     import ctypes
     from svo_raytracer_amd import hiplib
     from svo_raytracer_amd.cameras import CAMERAS
@@ -188,7 +188,7 @@ def test_config3_through_the_jni_ring(pool8192):
 
     z = np.load(GOLD)
     step = int(z["step"][0])
-    w, h, nd, nb = 1920, 1080, 4, 5
+    w, h, nd, nb = 1920, 1080, 6, 4      # bench.py's default shape: 6 submissions in flight x 4 frames
     j = nCreate(0)
     assert j != 0
     try:
