@@ -101,7 +101,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
                                            unsigned long long act, const int threshold, const unsigned long long cone_lanes,
                                            uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
-  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp;
+  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, six, siy, siz;
   int cnt;
 #ifdef SVO_STAMPS
 #define SVO_RFL(i) (uint32_t) __builtin_amdgcn_readfirstlane((int)mix[i])
@@ -121,13 +121,15 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_bfe_u32 %[t0], %[px], %[scale], 1\n\t"
       "v_bfe_u32 %[t1], v56, %[scale], 1\n\t"
       "v_bfe_u32 %[t2], v57, %[scale], 1\n\t"
+      "v_cmp_ne_u32_e64 %[six], 0, %[t0]\n\t"                     // lanes in the upper half of their parent, per axis
+      "v_cmp_ne_u32_e64 %[siy], 0, %[t1]\n\t"
+      "v_cmp_ne_u32_e64 %[siz], 0, %[t2]\n\t"
       "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"
       "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n\t"                  // idx = x | y << 1 | z << 2
       "v_xor_b32 %[cs], %[t0], %[oct]\n\t"                        // cs = idx ^ octant
       "v_add_u32 %[iter], 1, %[iter]\n\t"                         // iter++
       "v_cmp_lt_u32 vcc, 0x5dc, %[iter]\n\t"                      // iter > 1500
       "v_lshlrev_b32_e64 %[bit], %[cs], %[k101]\n\t"              // bit cs of the ne byte and of the has byte
-      "s_mov_b64 %[sp], 0\n\t"
       "s_cmp_lg_u64 vcc, 0\n\t"
       "s_cbranch_scc1 Lcap%=\n"                                   // rare, out of line
       "Lnocap%=:\n\t"
@@ -155,9 +157,13 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_cndmask_b32_e64 %[t0], 0, v58, vcc\n\t"                  // per-axis decrement: the cell size or 0
       "v_cndmask_b32_e64 v62, 0, v58, %[sg]\n\t"
       "v_cndmask_b32_e64 v63, 0, v58, %[sh]\n\t"
-      "v_cndmask_b32_e64 %[t2], 0, 1, %[sh]\n\t"
-      "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], %[sg]\n\t"
-      "v_addc_co_u32_e64 %[t2], %[sf], %[t2], %[t2], vcc\n\t"     // step mask
+      // an axis that steps out of the lower half leaves the parent: POP (svotrace.comp:341; idx & step after the flip =
+      // step & ~idx before it) -- on lane sets, no step mask in a register
+      "s_andn2_b64 %[sp], vcc, %[six]\n\t"
+      "s_andn2_b64 %[sf], %[sg], %[siy]\n\t"
+      "s_or_b64 %[sp], %[sp], %[sf]\n\t"
+      "s_andn2_b64 %[sf], %[sh], %[siz]\n\t"
+      "s_or_b64 %[sp], %[sp], %[sf]\n\t"
       "s_waitcnt vmcnt(0)\n\t"
       "v_and_b32 %[bit], %[bit], v65\n\t"
       "v_cmp_ne_u32_sdwa %[sa], %[bit], %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // child not empty
@@ -167,6 +173,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = not empty & in range & !at LOD & inside & child block
       "s_and_b64 %[se], %[se], %[sa]\n\t"                 // not empty & in range & (at LOD | inside)
       "s_andn2_b64 %[sa], exec, %[se]\n\t"                // ADVANCE = the rest
+      "s_and_b64 %[sp], %[sp], %[sa]\n\t"                 // POP = the advancing lanes that leave their parent
       "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = not empty & in range & (at LOD | (inside & no child block))
       "s_mov_b64 exec, %[se]\n\t"
       "v_mov_b32 %[st], 2\n\t"                            // ST_HIT
@@ -212,10 +219,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_mov_b32 %[tmin], %[tcm]\n\t"                     // t_min = tc_max
       "v_sub_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[56:57], v[56:57], v[62:63] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "v_bitop3_b32 %[t2], %[t2], %[cs], %[oct] bitop3:0x90\n\t"   // step & ~idx (idx = cs ^ octant): an axis stepped out of the lower half
-      "v_cmp_ne_u32 vcc, 0, %[t2]\n\t"                    // left the parent: POP
-      "s_mov_b64 %[sp], vcc\n\t"
-      "s_mov_b64 exec, vcc\n\t"
+      "s_mov_b64 exec, %[sp]\n\t"                         // left the parent: POP
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
@@ -271,7 +275,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
         [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
-        [sp] "=&s"(sp), [cnt] "=&s"(cnt)
+        [sp] "=&s"(sp), [six] "=&s"(six), [siy] "=&s"(siy), [siz] "=&s"(siz), [cnt] "=&s"(cnt)
 #ifdef SVO_STAMPS
         , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
 #endif
