@@ -410,7 +410,10 @@ def main(argv=None, ctx_factory=None):
             "alg_bytes_per_launch": int(my_alg * batch),
             "note": "a launch carries %d frame(s) and %d launches overlap, so kernel_ms > ms_per_step (= one frame); achieved = "
                     "bytes per frame / ms_per_step (device level), achieved_per_launch = bytes per launch / kernel_ms; "
-                    "kernel_ms_isolated = one frame at a time, GPU filled by one launch; traffic is per frame" % (batch, nbuf),
+                    "kernel_ms_isolated = one frame at a time, GPU filled by one launch; traffic is per frame.  kernel_ms is taken between "
+                    "HIP events around the launch on its slot's stream (svo_ring_query): with more launches in flight than fit the CUs "
+                    "at once it includes the launch's wait for CU slots, which rocprofv3's kernel duration (first wave to last, "
+                    "profiles/round3_bench_default_rocprofv3.txt) does not; one launch at a time the two agree" % (batch, nbuf),
         }
         if pmc:
             # the roof that binds: instruction issue.  Wave-level VALU instructions per launch x 2.5 cycles over
@@ -451,6 +454,7 @@ def main(argv=None, ctx_factory=None):
                 "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": int(round(nan_rays)),
                 "scene_build_s": round(t_build, 2), "frames_in_flight": nbuf * batch, "launches_in_flight": nbuf,
                 "frames_per_launch": batch, "use_beam": args.beam,
+                "descriptor_table": (ctx.derived_info() if (args.pipeline == 1 and hasattr(ctx, "derived_info")) else None),
                 "verification": vinfo,
             },
             "roofline": roof,
