@@ -103,13 +103,6 @@ __global__ __launch_bounds__(256) void place_kernel(const uint8_t *pool_base, ui
   aux[j] = ck;
 }
 
-struct Scratch {
-  uint16_t *masks = nullptr;
-  uint8_t *hasmask = nullptr;
-  uint32_t *first = nullptr;
-  size_t cap = 0;
-};
-
 // Expand the states [lo, lo + n): returns how many child states were appended at `next` (0xffffffff on overflow of the
 // budget); with last_level set nothing is appended and the return value is the number of children that WOULD have
 // been (non-zero = the pool is deeper than the table).
@@ -131,15 +124,27 @@ inline uint32_t expand(build::Builder &B, Table &t, const uint8_t *pool, uint32_
   return total;
 }
 
+// One attempt with room for `want` states; *overflow is set when the unrolling needed more.
+inline hipError_t build_table_sized(Table &t, const uint8_t *d_pool, uint32_t pool_len, size_t want, hipStream_t stream, bool *overflow);
+
 // (Re)build the table for the pool.  hipSuccess with t.ok = false means "not derivable, use the byte walk".
+// Budget: a proper tree has one state per interior node with a child block, i.e. per >= 7 + 8 bytes of pool -- the first
+// attempt allocates for that (8192^3 bench scene: 67.7 M states of 96 M); pools whose phantom / overlapping children
+// unroll into more get a second attempt with one state per 8 bytes of pool; beyond that the records are walked.
 inline hipError_t build_table(Table &t, const uint8_t *d_pool, uint64_t pool_len64, hipStream_t stream) {
   const uint32_t pool_len = (uint32_t)pool_len64;
+  bool overflow = false;
+  hipError_t e = build_table_sized(t, d_pool, pool_len, (size_t)pool_len / 15 + 4096, stream, &overflow);
+  if (e != hipSuccess || !overflow) return e;
+  return build_table_sized(t, d_pool, pool_len, (size_t)pool_len / 8 + 4096, stream, &overflow);
+}
+
+inline hipError_t build_table_sized(Table &t, const uint8_t *d_pool, uint32_t pool_len, size_t want, hipStream_t stream, bool *overflow) {
+  *overflow = false;
   t.ok = false; t.count = 0; t.levels = 0;
-  // budget: a proper tree has one state per interior node with a child block (>= 7 + 8 bytes of pool each)
-  const size_t want = (size_t)pool_len / 8 + 4096;
   if (want >= (1u << 28)) return hipSuccess;   // descriptor byte offsets must fit 31 bits
   hipError_t e;
-  if (t.cap < want || t.cap > 4 * want) {
+  if (t.cap < want || t.cap > 2 * want) {
     if (t.desc) (void)hipFree(t.desc);
     if (t.aux) (void)hipFree(t.aux);
     t.desc = nullptr; t.aux = nullptr; t.cap = 0;
@@ -173,7 +178,7 @@ inline hipError_t build_table(Table &t, const uint8_t *d_pool, uint64_t pool_len
   for (; depth < kLevels && n > 0; depth++) {
     const bool last = depth == kLevels - 1;
     const uint32_t got = expand(B, t, d_pool, pool_len, lo, n, end, last);
-    if (got == 0xffffffffu) { ok = false; break; }
+    if (got == 0xffffffffu) { ok = false; *overflow = B.err == hipSuccess; break; }
     if (last) { if (got) ok = false; break; }
     lo = end; n = got; end += got;
   }
@@ -205,7 +210,7 @@ inline hipError_t build_table(Table &t, const uint8_t *d_pool, uint64_t pool_len
       if (!ph_known[nph]) ph_desc[nph] = make_uint2(0u, 0u);
       nph++;
     }
-    if ((uint64_t)end + nph > t.cap) ok = false;
+    if ((uint64_t)end + nph > t.cap) { ok = false; *overflow = true; }
     if (ok) {
       const uint2 phd = make_uint2(end * 8u, m_ne | (m_has << 8));
       if ((e = hipMemcpyAsync(t.desc + kPhantom, &phd, sizeof phd, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
@@ -220,14 +225,14 @@ inline hipError_t build_table(Table &t, const uint8_t *d_pool, uint64_t pool_len
       for (uint32_t k = 0; k < nph && ok; k++) {
         if (ph_known[k]) continue;
         const uint32_t got = expand(B, t, d_pool, pool_len, ph0 + k, 1, end, false);
-        if (got == 0xffffffffu) { ok = false; break; }
+        if (got == 0xffffffffu) { ok = false; *overflow = B.err == hipSuccess; break; }
         end += got;
       }
       uint32_t n2 = end - lo2;
       for (int d = 2; d < kLevels && n2 > 0 && ok; d++) {
         const bool last = d == kLevels - 1;
         const uint32_t got = expand(B, t, d_pool, pool_len, lo2, n2, end, last);
-        if (got == 0xffffffffu) { ok = false; break; }
+        if (got == 0xffffffffu) { ok = false; *overflow = B.err == hipSuccess; break; }
         if (last) { if (got) ok = false; break; }
         lo2 = end; n2 = got; end += got;
       }
