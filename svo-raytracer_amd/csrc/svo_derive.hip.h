@@ -157,6 +157,10 @@ inline hipError_t build_table_sized(Table &t, const uint8_t *d_pool, uint32_t po
   (void)hipEventRecord(e0, stream);
   build::Builder B;
   B.stream = stream;
+  struct Cleanup {   // whichever way the function is left: scratch and events go
+    build::Builder &b; hipEvent_t &a, &z;
+    ~Cleanup() { b.release(); if (a) (void)hipEventDestroy(a); if (z) (void)hipEventDestroy(z); }
+  } cleanup{B, e0, e1};
   // the first 64 bytes of the pool on the host: the root record and the records the phantom state sees
   uint8_t head[64];
   if ((e = hipMemcpyAsync(head, d_pool, 64, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -242,9 +246,7 @@ inline hipError_t build_table_sized(Table &t, const uint8_t *d_pool, uint32_t po
   e = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = B.err;
   if (e == hipSuccess) e = hipGetLastError();
-  (void)hipEventElapsedTime(&t.build_ms, e0, e1);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  B.release();
+  if (e == hipSuccess) (void)hipEventElapsedTime(&t.build_ms, e0, e1);
   if (e != hipSuccess) return e;
   t.count = end;
   t.ok = ok;

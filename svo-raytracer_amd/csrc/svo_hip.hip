@@ -81,6 +81,7 @@ struct svo_ctx {
     uint32_t *seq_word = nullptr;
   };
   std::vector<void *> ipc_opened;
+  std::vector<void *> dev_allocs;   // svo_dev_alloc, freed with the context at the latest
   std::vector<RingSlot> ring;
   int reserved_cus = 0;        // CUs per XCD the ring's streams leave free (svo_set_reserved_cus)
   int ring_frames = 0;
@@ -174,6 +175,7 @@ int svo_destroy(svo_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   ring_free(c);
   for (void *p : c->ipc_opened) if (p) (void)hipIpcCloseMemHandle(p);
+  for (void *p : c->dev_allocs) if (p) (void)hipFree(p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return SVO_OK;
@@ -976,6 +978,7 @@ int svo_dev_alloc(svo_ctx *c, uint64_t nbytes, void **dptr) {
   if (!c || !dptr || nbytes == 0) return fail(c, SVO_E_INVALID, "svo_dev_alloc: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMalloc(dptr, nbytes));
+  c->dev_allocs.push_back(*dptr);
   HIPCHK(c, hipMemset(*dptr, 0, nbytes));
   HIPCHK(c, hipDeviceSynchronize());
   return SVO_OK;
@@ -984,8 +987,9 @@ int svo_dev_free(svo_ctx *c, void *dptr) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  if (dptr) HIPCHK(c, hipFree(dptr));
-  return SVO_OK;
+  for (auto &p : c->dev_allocs)
+    if (p && p == dptr) { p = nullptr; HIPCHK(c, hipFree(dptr)); return SVO_OK; }
+  return dptr ? fail(c, SVO_E_INVALID, "svo_dev_free: not allocated by this context") : SVO_OK;
 }
 int svo_dev_read(svo_ctx *c, const void *dptr, void *host, uint64_t nbytes) {
   if (!c || !dptr || !host) return fail(c, SVO_E_INVALID, "svo_dev_read: null pointer");
