@@ -195,3 +195,35 @@ def test_pool_written_through_the_device_pointer_needs_commit(ctx):
         ref = oracle.render(b, w, h, CAMERAS["K1"], 2, 0)
         assert (got["rgba"] == ref["rgba"]).all() and (got["hits"]["pointer"] == ref["hits"]["pointer"]).all()
     ctx.pool_upload(scene.build_scene(256)[0])              # what the module's other tests expect
+
+
+def test_ring_streams_with_reserved_cus_and_device_memory_calls(ctx):
+    """svo_set_reserved_cus: the next ring's streams carry a CU mask (one CU per XCD left free); same frames.
+    svo_dev_alloc / _read / _free and the IPC calls' argument checks."""
+    from svo_raytracer_amd.hiplib import SvoError
+    w, h = 160, 96
+    ctx.set_pipeline(1)
+    ctx.resize(w, h)
+    want = {f: _alone(ctx, w, h, f, 0) for f in range(2, 8)}
+    ctx.set_params(2, 0, 0, 0, 2, 0, 1)
+    for reserve in (1, 2, 0):
+        ctx.set_reserved_cus(reserve)
+        ctx.ring_create(2, 3, want_hits=True)
+        s0, s1 = ctx.ring_submit(2, 3), ctx.ring_submit(5, 3)
+        for s, first in ((s0, 2), (s1, 5)):
+            for k in range(3):
+                _eq(ctx.ring_read(s, k, want_hits=True), want[first + k])
+        ctx.ring_destroy()
+    with pytest.raises(SvoError):
+        ctx.set_reserved_cus(17)
+    p = ctx.dev_alloc(4096)
+    assert (ctx.dev_read(p, 4096) == 0).all()        # zeroed
+    handle = ctx.ipc_export(p)
+    assert len(handle) == 64
+    with pytest.raises(SvoError):
+        ctx.dev_free(p + 8)                           # not an allocation of this context
+    ctx.dev_free(p)
+    with pytest.raises(SvoError):
+        ctx.dev_free(p)                               # already freed
+    with pytest.raises(SvoError):
+        ctx.ipc_close(12345)
