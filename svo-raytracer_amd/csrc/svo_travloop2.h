@@ -23,6 +23,13 @@ namespace svo {
 
 // SVO_DESC_LOAD_EARLY=1: the descending lanes' load leaves inside the descend section (more instructions between the
 // load and its use) and the popping lanes issue a second one; 0: one load per trip for both.
+// SVO_EXEC_STEPS=1: the per-axis position updates of a descend / an advance are subtractions under an EXEC mask (the lane
+// set of the axis' compare) instead of v_cndmask-selected increments added to every lane: v_cndmask (like every compare,
+// min / max, bit-field, shift-add and packed-f32 instruction) issues at half the rate of v_add / v_sub / logic ops on gfx950
+// (tools/calib_valu2.hip: 4.2 against 2.4 cycles per wave64 instruction), the scalar unit runs beside the vector ALU.
+#ifndef SVO_EXEC_STEPS
+#define SVO_EXEC_STEPS 1
+#endif
 #ifndef SVO_DESC_LOAD_EARLY
 #define SVO_DESC_LOAD_EARLY 0
 #endif
@@ -101,7 +108,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
                                            unsigned long long act, const int threshold, const unsigned long long cone_lanes,
                                            uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
-  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, six, siy, siz;
+  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sx, six, siy, siz;
   int cnt;
 #ifdef SVO_STAMPS
 #define SVO_RFL(i) (uint32_t) __builtin_amdgcn_readfirstlane((int)mix[i])
@@ -151,15 +158,22 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_andn2_b64 %[sd], %[sc], %[sb]\n\t"
       "s_and_b64 %[sd], %[sd], %[sa]\n\t"                         // in range & !at LOD & inside: descends if it has a child block
       // the ADVANCE step of every active lane, while the descriptor of lanes that descended / popped is in flight
+#if SVO_EXEC_STEPS
+      "v_cmp_le_f32_e64 %[sx], %[tcx], %[tcm]\n\t"                // the axes whose exit distance is the cell's
+      "v_cmp_le_f32_e64 %[sg], v60, %[tcm]\n\t"
+      "v_cmp_le_f32_e64 %[sh], v61, %[tcm]\n\t"
+#else
       "v_cmp_le_f32 vcc, %[tcx], %[tcm]\n\t"
       "v_cmp_le_f32_e64 %[sg], v60, %[tcm]\n\t"
       "v_cmp_le_f32_e64 %[sh], v61, %[tcm]\n\t"
       "v_cndmask_b32_e64 %[t0], 0, v58, vcc\n\t"                  // per-axis decrement: the cell size or 0
       "v_cndmask_b32_e64 v62, 0, v58, %[sg]\n\t"
       "v_cndmask_b32_e64 v63, 0, v58, %[sh]\n\t"
+      "s_mov_b64 %[sx], vcc\n\t"
+#endif
       // an axis that steps out of the lower half leaves the parent: POP (svotrace.comp:341; idx & step after the flip =
       // step & ~idx before it) -- on lane sets, no step mask in a register
-      "s_andn2_b64 %[sp], vcc, %[six]\n\t"
+      "s_andn2_b64 %[sp], %[sx], %[six]\n\t"
       "s_andn2_b64 %[sf], %[sg], %[siy]\n\t"
       "s_or_b64 %[sp], %[sp], %[sf]\n\t"
       "s_andn2_b64 %[sf], %[sh], %[siz]\n\t"
@@ -205,30 +219,64 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_cmp_gt_f32_e64 %[sc], v63, %[tmin]\n\t"
       "v_add_u32 %[scale], -1, %[scale]\n\t"
       "v_mov_b32 %[h], %[tcm]\n\t"                        // h = tc_max
+#if SVO_EXEC_STEPS
+      "v_mov_b32 %[tmax], %[t3]\n\t"                     // t_max = tv_max
+      "s_and_b64 exec, %[sd], vcc\n\t"                   // the upper half on an axis: position += half, under the compare's lane set
+      "v_add_f32 %[px], %[px], v58\n\t"
+      "s_and_b64 exec, %[sd], %[sb]\n\t"
+      "v_add_f32 v56, v56, v58\n\t"
+      "s_and_b64 exec, %[sd], %[sc]\n\t"
+      "v_add_f32 v57, v57, v58\n"
+#else
       "v_cndmask_b32_e64 %[t0], 0, v58, vcc\n\t"
       "v_cndmask_b32_e64 v62, 0, v58, %[sb]\n\t"
       "v_cndmask_b32_e64 v63, 0, v58, %[sc]\n\t"
       "v_add_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[56:57], v[56:57], v[62:63]\n\t"
       "v_mov_b32 %[tmax], %[t3]\n"                        // t_max = tv_max
+#endif
       "LnoD%=:\n\t"
       // ---- ADVANCE (svotrace.comp:329-339)
       "s_mov_b64 exec, %[sa]\n\t"
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c4", "c5", "exec")
       "v_mov_b32 %[tmin], %[tcm]\n\t"                     // t_min = tc_max
+#if SVO_EXEC_STEPS
+      "s_and_b64 exec, %[sa], %[sx]\n\t"                  // step: position -= cell size on the axes that leave the cell
+      "v_sub_f32 %[px], %[px], v58\n\t"
+      "s_and_b64 exec, %[sa], %[sg]\n\t"
+      "v_sub_f32 v56, v56, v58\n\t"
+      "s_and_b64 exec, %[sa], %[sh]\n\t"
+      "v_sub_f32 v57, v57, v58\n\t"
+#else
       "v_sub_f32 %[px], %[px], %[t0]\n\t"
       "v_pk_add_f32 v[56:57], v[56:57], v[62:63] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#endif
       "s_mov_b64 exec, %[sp]\n\t"                         // left the parent: POP
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
+#if SVO_EXEC_STEPS
+      // differing bits of the position before (= after + cell size, exact) and after the step, on the axes that stepped
+      "v_mov_b32 %[t0], 1\n\t"                            // (| 1 keeps ffbh defined)
+      "s_and_b64 exec, %[sp], %[sx]\n\t"
+      "v_add_f32 %[t1], %[px], v58\n\t"
+      "v_bitop3_b32 %[t0], %[t0], %[t1], %[px] bitop3:0xf6\n\t"   // a | (b ^ c)
+      "s_and_b64 exec, %[sp], %[sg]\n\t"
+      "v_add_f32 %[t1], v56, v58\n\t"
+      "v_bitop3_b32 %[t0], %[t0], %[t1], v56 bitop3:0xf6\n\t"
+      "s_and_b64 exec, %[sp], %[sh]\n\t"
+      "v_add_f32 %[t1], v57, v58\n\t"
+      "v_bitop3_b32 %[t0], %[t0], %[t1], v57 bitop3:0xf6\n\t"
+      "s_mov_b64 exec, %[sp]\n\t"
+#else
       "v_add_f32 %[t0], %[px], %[t0]\n\t"                 // position before the step (exact)
       "v_pk_add_f32 v[62:63], v[56:57], v[62:63]\n\t"
       "v_xor_b32 %[t0], %[t0], %[px]\n\t"
       "v_xor_b32 %[t1], v62, v56\n\t"
       "v_bitop3_b32 %[t0], %[t0], v63, v57 bitop3:0xf6\n\t"   // a | (b ^ c)
       "v_or3_b32 %[t0], %[t0], %[t1], 1\n\t"              // differing bits (| 1 keeps ffbh defined)
+#endif
       "v_ffbh_u32 %[t0], %[t0]\n\t"
       "v_sub_u32 %[t2], 20, %[t0]\n\t"                    // scale - 11
       "v_xor_b32 %[scale], 31, %[t0]\n\t"                 // scale = 31 - leading zeros
@@ -275,7 +323,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
         [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
-        [sp] "=&s"(sp), [six] "=&s"(six), [siy] "=&s"(siy), [siz] "=&s"(siz), [cnt] "=&s"(cnt)
+        [sp] "=&s"(sp), [sx] "=&s"(sx), [six] "=&s"(six), [siy] "=&s"(siy), [siz] "=&s"(siz), [cnt] "=&s"(cnt)
 #ifdef SVO_STAMPS
         , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
 #endif
