@@ -90,6 +90,10 @@ KERNEL(k_cmpcnd, OPS("v_cmp_lt_f32 vcc, %[a0], %[b]", "v_add_f32 %[a1], %[a1], %
                      "v_cmp_lt_f32 vcc, %[a4], %[b]", "v_add_f32 %[a5], %[a5], %[b]", "v_add_f32 %[a6], %[a6], %[b]", "v_cndmask_b32_e64 %[a7], %[a7], %[b], vcc"))
 KERNEL(k_execsub, OPS("s_and_b64 exec, %[s0], %[s1]", "v_sub_f32 %[a0], %[a0], %[b]", "s_and_b64 exec, %[s0], %[s2]", "v_sub_f32 %[a1], %[a1], %[b]",
                       "s_and_b64 exec, %[s0], %[s3]", "v_sub_f32 %[a2], %[a2], %[b]", "s_mov_b64 exec, -1", "v_add_f32 %[a3], %[a3], %[b]"))
+KERNEL(k_cmpcnd32, OPS("v_cmp_lt_f32 vcc, %[a0], %[b]", "v_cndmask_b32 %[a1], %[a1], %[b], vcc", "v_cmp_lt_f32 vcc, %[a2], %[b]", "v_cndmask_b32 %[a3], %[a3], %[b], vcc",
+                       "v_cmp_lt_f32 vcc, %[a4], %[b]", "v_cndmask_b32 %[a5], %[a5], %[b], vcc", "v_cmp_lt_f32 vcc, %[a6], %[b]", "v_cndmask_b32 %[a7], %[a7], %[b], vcc"))
+KERNEL(k_cmpcnd32b, OPS("v_cmp_lt_f32 vcc, %[a0], %[b]", "v_cndmask_b32 %[a1], %[a1], %[b], vcc", "v_cndmask_b32 %[a2], %[a2], %[b], vcc", "v_cndmask_b32 %[a3], %[a3], %[b], vcc",
+                        "v_cmp_lt_f32 vcc, %[a4], %[b]", "v_cndmask_b32 %[a5], %[a5], %[b], vcc", "v_cndmask_b32 %[a6], %[a6], %[b], vcc", "v_cndmask_b32 %[a7], %[a7], %[b], vcc"))
 KERNEL(k_salu, OPS("s_and_b64 %[s0], %[s0], %[s1]", "s_andn2_b64 %[s1], %[s1], %[s2]", "s_or_b64 %[s2], %[s2], %[s3]", "s_and_b64 %[s3], %[s3], %[s0]",
                    "s_or_b64 %[s0], %[s0], %[s2]", "s_andn2_b64 %[s1], %[s1], %[s3]", "s_or_b64 %[s2], %[s2], %[s0]", "s_and_b64 %[s3], %[s3], %[s1]"))
 KERNEL(k_mix, OPS("v_add_f32 %[a0], %[a0], %[b]", "s_and_b64 %[s0], %[s0], %[s1]", "v_add_f32 %[a1], %[a1], %[b]", "s_or_b64 %[s2], %[s2], %[s3]",
@@ -113,6 +117,7 @@ int main() {
   run("v_ffbh_u32", k_ffbh, out); run("v_bitop3_b32", k_bitop3, out); run("v_bfm_b32", k_bfm, out);
   run("v_cndmask_b32 (vcc)", k_cnd32, out); run("v_cndmask_b32_e64 (sgpr)", k_cnd64, out); run("v_cndmask_e64 0, v, sgpr", k_cndc, out);
   run("v_cndmask_e64 v, v, vcc", k_cnd64v, out); run("cmp vcc; 2 adds; cndmask_e64 vcc", k_cmpcnd, out); run("3 x (s_and exec; v_sub) + mov exec + add", k_execsub, out);
+  run("4 x (cmp vcc; cndmask VOP2 vcc)", k_cmpcnd32, out); run("2 x (cmp vcc; 3 cndmask VOP2 vcc)", k_cmpcnd32b, out);
   run("v_lshrrev_b32", k_lshr, out); run("v_lshlrev_b32_e64", k_lshle64, out); run("v_and_b32", k_and, out); run("v_or3_b32", k_or3, out); run("v_sub_f32", k_subf, out); run("v_min_u32", k_minu, out);
   run("v_lshrrev_b32 by vgpr", k_lshrv, out); run("v_lshlrev_b32 by vgpr", k_lshlv, out); run("v_mad_u32_u24", k_mad24, out); run("v_mul_u32_u24", k_mul24, out);
   run("v_bfi_b32", k_bfi, out); run("v_and_or_b32", k_andor, out); run("v_add3_u32", k_add3, out); run("v_perm_b32", k_perm, out); run("v_max_f32", k_maxf, out);
