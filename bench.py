@@ -48,7 +48,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 1024            # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
-VALU_CYCLES = 2.5       # measured: a SIMD retires one wave64 VALU instruction per ~2.5 cycles (profiles/r01b_calib_valu.txt)
+# gfx950 issues wave64 VALU instructions in two classes (tools/calib_valu2.hip, profiles/round3_calib_valu2.txt; 6 waves per
+# SIMD): add / sub / mul / fma / logic / mov / right shift / v_bitop3 one per ~2.35 cycles, compares, v_cndmask, min / max,
+# bit-field, shift-and-add, count and packed-f32 ops one per ~4.3.  The traversal trip (svo_travloop2.h) is 36 of the first
+# and 43 of the second: 3.41 cycles per instruction; the round code is taken to mix alike.
+VALU_CYCLES = (36 * 2.35 + 43 * 4.3) / 79.0
 
 # frames per dispatch when --batch is not given (the same for every number of GPUs, so that the scaling curve compares like
 # with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N.
@@ -427,6 +431,8 @@ def main(argv=None, ctx_factory=None):
                 "valu_insts_per_frame": int(pmc["sq_insts_valu"] / batch),
                 "valu_issue_frac": round(pmc["sq_insts_valu"] / batch * VALU_CYCLES / (SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4),
                 "valu_lane_util": round(pmc["sq_thread_cycles_valu"] / (64.0 * pmc["sq_active_inst_valu"]), 4),
+                "cycles_per_valu_inst": round(VALU_CYCLES, 3),
+                "note": "model: instructions x class-weighted issue cycles / (1024 SIMDs x 2.4 GHz x time); ~1 = the vector issue pipe is saturated",
                 "src_hash": pmc["src_hash"], "from": "profiles/pmc_per_launch.json",
             }
         stripes = "%d GPU(s) x interleaved tile rows (%d pixel rows each), gathered to rank 0" % (world, ring.rows_per_rank)
