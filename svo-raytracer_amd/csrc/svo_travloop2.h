@@ -27,6 +27,18 @@ namespace svo {
 // set of the axis' compare) instead of v_cndmask-selected increments added to every lane: v_cndmask (like every compare,
 // min / max, bit-field, shift-add and packed-f32 instruction) issues at half the rate of v_add / v_sub / logic ops on gfx950
 // (tools/calib_valu2.hip: 4.2 against 2.4 cycles per wave64 instruction), the scalar unit runs beside the vector ALU.
+#ifndef SVO_CAP_CARRY
+#define SVO_CAP_CARRY 1
+#endif
+#ifndef SVO_HIT_LATE
+#define SVO_HIT_LATE 1
+#endif
+#ifndef SVO_BIT_SHR
+#define SVO_BIT_SHR 1
+#endif
+#ifndef SVO_NO_PK
+#define SVO_NO_PK 1
+#endif
 #ifndef SVO_EXEC_STEPS
 #define SVO_EXEC_STEPS 1
 #endif
@@ -108,7 +120,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
                                            unsigned long long act, const int threshold, const unsigned long long cone_lanes,
                                            uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
-  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sx, six, siy, siz;
+  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sm, sx, six, siy, siz;
   int cnt;
 #ifdef SVO_STAMPS
 #define SVO_RFL(i) (uint32_t) __builtin_amdgcn_readfirstlane((int)mix[i])
@@ -119,8 +131,14 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
 #endif
   uint32_t t0, t1, t2, t3, bit;
   float tcx, tcm;
+#if SVO_CAP_CARRY
+  r.iter += 0u - (kMaxIter + 1u);
+#endif
   asm volatile(
-      "s_mov_b64 %[sv], exec\n"
+      "s_mov_b64 %[sv], exec\n\t"
+#if SVO_HIT_LATE
+      "s_mov_b64 %[sm], %[act]\n"
+#endif
       "Ltrip%=:\n\t"
       "s_mov_b64 exec, %[act]\n\t"
       SVO_COUNT("c0", "c1", "exec")
@@ -134,18 +152,34 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"
       "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n\t"                  // idx = x | y << 1 | z << 2
       "v_xor_b32 %[cs], %[t0], %[oct]\n\t"                        // cs = idx ^ octant
+#if SVO_CAP_CARRY
+      "v_add_co_u32 %[iter], vcc, 1, %[iter]\n\t"                 // iter++ on a counter biased by 2^32 - 1501: the carry is "iter > 1500"
+#else
       "v_add_u32 %[iter], 1, %[iter]\n\t"                         // iter++
       "v_cmp_lt_u32 vcc, 0x5dc, %[iter]\n\t"                      // iter > 1500
+#endif
+#if !SVO_BIT_SHR
       "v_lshlrev_b32_e64 %[bit], %[cs], %[k101]\n\t"              // bit cs of the ne byte and of the has byte
+#endif
       "s_cmp_lg_u64 vcc, 0\n\t"
       "s_cbranch_scc1 Lcap%=\n"                                   // rare, out of line
       "Lnocap%=:\n\t"
       // ---- exit distances of the current cell (svotrace.comp:268-269)
       "v_mul_f32 %[tcx], %[px], %[cx]\n\t"
+#if SVO_NO_PK
+      "v_mul_f32 v60, v56, %[cy]\n\t"
+      "v_mul_f32 v61, v57, %[cz]\n\t"
+#else
       "v_pk_mul_f32 v[60:61], v[56:57], %[cyz]\n\t"
+#endif
       "v_cmp_lt_f32 vcc, %[k005], %[tmin]\n\t"                    // t_min > 0.05 ...
       "v_sub_f32 %[tcx], %[tcx], %[bx]\n\t"
+#if SVO_NO_PK
+      "v_sub_f32 v60, v60, %[by]\n\t"
+      "v_sub_f32 v61, v61, %[bz]\n\t"
+#else
       "v_pk_add_f32 v[60:61], v[60:61], %[byz] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#endif
       "s_and_b64 vcc, vcc, %[conem]\n\t"                          // ... on a cone (secondary) ray: LOD 11 from here on (sticky)
       "v_cmp_le_f32_e64 %[sa], %[tmin], %[tmax]\n\t"              // t_min <= t_max
       "v_min3_f32 %[tcm], %[tcx], v60, v61\n\t"                   // tc_max
@@ -179,7 +213,12 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_andn2_b64 %[sf], %[sh], %[siz]\n\t"
       "s_or_b64 %[sp], %[sp], %[sf]\n\t"
       "s_waitcnt vmcnt(0)\n\t"
+#if SVO_BIT_SHR
+      "v_lshrrev_b32 %[bit], %[cs], v65\n\t"            // bit cs of the ne byte -> bit 0, of the has byte -> bit 8
+      "v_and_b32 %[bit], %[k101], %[bit]\n\t"
+#else
       "v_and_b32 %[bit], %[bit], v65\n\t"
+#endif
       "v_cmp_ne_u32_sdwa %[sa], %[bit], %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // child not empty
       "v_cmp_ne_u32_sdwa vcc, %[bit], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"     // child has a child block
       // lane sets
@@ -189,8 +228,10 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_andn2_b64 %[sa], exec, %[se]\n\t"                // ADVANCE = the rest
       "s_and_b64 %[sp], %[sp], %[sa]\n\t"                 // POP = the advancing lanes that leave their parent
       "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = not empty & in range & (at LOD | (inside & no child block))
+#if !SVO_HIT_LATE
       "s_mov_b64 exec, %[se]\n\t"
       "v_mov_b32 %[st], 2\n\t"                            // ST_HIT
+#endif
       "s_andn2_b64 %[act], %[act], %[se]\n\t"
       // ---- DESCEND (svotrace.comp:291-327)
       "s_mov_b64 exec, %[sd]\n\t"
@@ -211,9 +252,19 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_lshl_add_u32 %[self], %[t1], 3, v64\n\t"         // the child's descriptor
       SVO_DESC_LOAD_D
       "v_mul_f32 %[t0], %[cx], v58\n\t"
+#if SVO_NO_PK
+      "v_mul_f32 v62, %[cy], v58\n\t"
+      "v_mul_f32 v63, %[cz], v58\n\t"
+#else
       "v_pk_mul_f32 v[62:63], %[cyz], v[58:59] op_sel_hi:[1,0]\n\t"
+#endif
       "v_add_f32 %[t0], %[t0], %[tcx]\n\t"                // centre distances
+#if SVO_NO_PK
+      "v_add_f32 v62, v62, v60\n\t"
+      "v_add_f32 v63, v63, v61\n\t"
+#else
       "v_pk_add_f32 v[62:63], v[62:63], v[60:61]\n\t"
+#endif
       "v_cmp_gt_f32 vcc, %[t0], %[tmin]\n\t"
       "v_cmp_gt_f32_e64 %[sb], v62, %[tmin]\n\t"
       "v_cmp_gt_f32_e64 %[sc], v63, %[tmin]\n\t"
@@ -307,15 +358,25 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_mov_b64 exec, vcc\n\t"
       "v_mov_b32 %[st], 4\n\t"
       "s_andn2_b64 %[act], %[act], vcc\n\t"
+#if SVO_HIT_LATE
+      "s_andn2_b64 %[sm], %[sm], vcc\n\t"
+#endif
       "s_mov_b64 exec, %[act]\n\t"
       "s_branch Lnocap%=\n"
       "Lmiss%=:\n\t"                                      // left the octree: status = ST_MISS
       "s_mov_b64 exec, vcc\n\t"
       "v_mov_b32 %[st], 3\n\t"
       "s_andn2_b64 %[act], %[act], vcc\n\t"
+#if SVO_HIT_LATE
+      "s_andn2_b64 %[sm], %[sm], vcc\n\t"
+#endif
       "s_andn2_b64 %[sp], %[sp], vcc\n\t"
       "s_branch LnoA%=\n"
       "Lend%=:\n\t"
+#if SVO_HIT_LATE
+      "s_andn2_b64 exec, %[sm], %[act]\n\t"             // the lanes that stopped without leaving the octree or the budget: ST_HIT
+      "v_mov_b32 %[st], 2\n\t"
+#endif
       "s_waitcnt vmcnt(0)\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
       : [px] "+v"(r.px), "+{v[56:57]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v58}"(r.sexp), [h] "+v"(r.h),
@@ -323,13 +384,20 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
         [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
-        [sp] "=&s"(sp), [sx] "=&s"(sx), [six] "=&s"(six), [siy] "=&s"(siy), [siz] "=&s"(siz), [cnt] "=&s"(cnt)
+        [sp] "=&s"(sp), [sm] "=&s"(sm), [sx] "=&s"(sx), [six] "=&s"(six), [siy] "=&s"(siy), [siz] "=&s"(siz), [cnt] "=&s"(cnt)
 #ifdef SVO_STAMPS
         , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
 #endif
-      : [cx] "v"(r.cx), [bx] "v"(r.bx), [cyz] "v"(r.cyz), [byz] "v"(r.byz), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
+      : [cx] "v"(r.cx), [bx] "v"(r.bx),
+#if !SVO_NO_PK
+        [cyz] "v"(r.cyz), [byz] "v"(r.byz),
+#endif
+        [cy] "v"(r.cyz.x), [cz] "v"(r.cyz.y), [by] "v"(r.byz.x), [bz] "v"(r.byz.y), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
         [lds8] "v"(lds8), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
       : "vcc", "scc", "memory", "v59", "v60", "v61", "v62", "v63");
+#if SVO_CAP_CARRY
+  r.iter += kMaxIter + 1u;
+#endif
 #ifdef SVO_STAMPS
   mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7;
 #endif
