@@ -128,6 +128,7 @@ struct ByteWalk {
     return trav_init(root, t, o, d, cone, t_start);
 #endif
   }
+  __device__ __forceinline__ void fresh_stack(Stack &, uint32_t) const {}   // the record walk keeps a "pushed" mask per ray
   __device__ __forceinline__ Cast result(const State &t, int status) const {
 #if SVO_ASM_LOOP
     return trav_result_regs(pool, t, status);
@@ -176,6 +177,16 @@ struct DescWalk {
     return trav_init_regs2(rootd, t, o, d, cone, t_start);
 #else
     return trav_init2(rootd, t, o, d, cone, t_start);
+#endif
+  }
+  // a new ray starts on a zeroed stack column, like the reference's zero-initialised stack[] (svotrace.comp:227): a pop to a
+  // level the ray never pushed then reads {descriptor 0, t_max 0} by itself, and the loop keeps no "pushed" mask
+  __device__ __forceinline__ void fresh_stack(Stack &stk, uint32_t lane) const {
+#if SVO_ASM_LOOP && SVO_STACK_CLEAR
+#pragma unroll
+    for (int lv = 0; lv < kStackLevels; ++lv) stk.pm[(lv << 6) | lane] = make_uint2(0u, 0u);
+#else
+    (void)stk; (void)lane;
 #endif
   }
   __device__ __forceinline__ Cast result(const State &t, int status) const {
@@ -451,6 +462,7 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
     // ---------------- set up the new rays: regenerated bounce / shadow rays and refilled primaries together
     if (ninit) {
       status = walk.init(t, io, d, icone, its);
+      walk.fresh_stack(stk, lane);
       if (kMode == 4) status = ST_MISS;   // no cast: straight to the (black) pixel
     }
     if (__ballot(status != ST_IDLE) == 0ull) {

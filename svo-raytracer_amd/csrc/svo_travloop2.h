@@ -27,6 +27,9 @@ namespace svo {
 // set of the axis' compare) instead of v_cndmask-selected increments added to every lane: v_cndmask (like every compare,
 // min / max, bit-field, shift-add and packed-f32 instruction) issues at half the rate of v_add / v_sub / logic ops on gfx950
 // (tools/calib_valu2.hip: 4.2 against 2.4 cycles per wave64 instruction), the scalar unit runs beside the vector ALU.
+#ifndef SVO_STACK_CLEAR
+#define SVO_STACK_CLEAR 1
+#endif
 #ifndef SVO_CAP_CARRY
 #define SVO_CAP_CARRY 1
 #endif
@@ -244,7 +247,9 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_and_saveexec_b64 %[sb], vcc\n\t"
       "v_lshl_add_u32 v63, %[t1], 9, %[lds8]\n\t"
       "ds_write2_b32 v63, %[self], %[tmax] offset1:1\n\t" // {parent state, t_max}
+#if !SVO_STACK_CLEAR
       "v_lshl_or_b32 %[wr], 1, %[t1], %[wr]\n\t"
+#endif
       "s_mov_b64 exec, %[sd]\n\t"
       "v_bfm_b32 %[t1], %[cs], 8\n\t"                     // the has bits of the children below cs
       "v_and_b32 %[t1], %[t1], v65\n\t"
@@ -334,8 +339,13 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_min_u32 %[t1], 11, %[t2]\n\t"
       "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"     // cell size = 2^(scale - 23)
       "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
+#if SVO_STACK_CLEAR
+      "ds_read_b32 %[self], %[t0]\n\t"                    // a level this ray never pushed holds the zeros it started on:
+      "ds_read_b32 %[tmax], %[t0] offset:4\n\t"           // state (0, 0) = descriptor 0, t_max 0
+#else
       "ds_read2_b32 v[62:63], %[t0] offset1:1\n\t"
       "v_bfe_i32 %[t2], %[wr], %[t2], 1\n\t"              // all ones if this ray pushed that level
+#endif
       "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
       "v_mov_b32 %[h], 0\n\t"                             // h = 0
       "v_and_b32 %[px], %[px], %[t3]\n\t"                 // round the position to the cell
@@ -343,8 +353,10 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_and_b32 v57, v57, %[t3]\n\t"
       "v_cmp_le_u32 vcc, 23, %[scale]\n\t"                // left the octree: MISS
       "s_waitcnt lgkmcnt(0)\n\t"
+#if !SVO_STACK_CLEAR
       "v_and_b32 %[self], %[t2], v62\n\t"                 // never pushed: state (0, 0) = descriptor 0, t_max 0
       "v_and_b32 %[tmax], %[t2], v63\n\t"
+#endif
       "s_cmp_lg_u64 vcc, 0\n\t"
       "s_cbranch_scc1 Lmiss%=\n"                          // out of line
       "LnoA%=:\n\t"
@@ -380,7 +392,10 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_waitcnt vmcnt(0)\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
       : [px] "+v"(r.px), "+{v[56:57]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v58}"(r.sexp), [h] "+v"(r.h),
-        [scale] "+v"(r.scale), [cs] "+v"(r.cs), [self] "+v"(r.self), "+{v64}"(r.dlo), "+{v65}"(r.dhi), [wr] "+v"(r.written),
+        [scale] "+v"(r.scale), [cs] "+v"(r.cs), [self] "+v"(r.self), "+{v64}"(r.dlo), "+{v65}"(r.dhi),
+#if !SVO_STACK_CLEAR
+        [wr] "+v"(r.written),
+#endif
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
         [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
