@@ -4,47 +4,34 @@
 // still traversing.  Against the byte walk's loop (svo_travloop.h) a trip loses: the child-offset arithmetic (two
 // shifts, a bit-op, an and, three popcounts, two mads: it is only needed for the hit pointer, once per cast, after the
 // loop), the two record loads of EVERY trip (the child's "empty" and "has a child block" bits come from the parent's
-// descriptor: one v_and + two v_cmp on a register), the cp / tag-mask extraction, and the 16-bit tag-mask plane of
-// the stack (a PUSH is one ds_write2_b32 of {descriptor offset, t_max}, a POP one ds_read2_b32).  What it gains is the
-// rank of the child among the parent's children with a child block (v_bfm, v_and, v_bcnt, v_lshl_add).
+// descriptor: a shift, an and and two v_cmp on a register), the cp / tag-mask extraction, the 16-bit tag-mask plane of
+// the stack and the pushed-levels mask (a PUSH is one ds_write2_b32 of {descriptor offset, t_max}; a POP two ds_read_b32
+// straight into the state registers: the caller zeroes a lane's stack column when it sets up a ray, so a level the ray
+// never pushed reads as the reference's zero-initialised entry).  What it gains is the rank of the child among the
+// parent's children with a child block (v_bfm, v_and, v_bcnt, v_lshl_add).
 //   trips load only for lanes that DESCEND or POP: one aligned 8-byte descriptor (49 cycles of the texture path per
 //   wave-level load against 2 x 34 for the two unaligned dwords of a record, tools/calib_td.hip), issued at the end
 //   of the trip for both lane sets together, waited for at the top of the next trip behind everything that does not
 //   need it (child slot, exit distances, the advance step).
 // Arithmetic, operand order and rounding are those of trav_step2() = trav_step() = svotrace.comp:262-369.
 //
-// Pinned registers: v[56:57] py,pz; v58 cell size (v[58:59] is the broadcast source of a packed multiply, v59 scratch);
-// v[60:61] tcy,tcz; v[62:63] temporaries; v[64:65] the parent's descriptor {first child descriptor, ne | has << 8}.
+// Pinned registers: v[56:57] py,pz; v58 cell size; v[60:61] tcy,tcz; v[62:63] temporaries; v[64:65] the parent's
+// descriptor {first child descriptor, ne | has << 8}.
+//
+// Which instructions: gfx950 issues a wave64 v_add / v_sub / v_mul / v_fma / logic op / v_mov / right shift / v_bitop3
+// every ~2.35 cycles per SIMD and every compare, v_cndmask, min / max, bit-field, shift-and-add, count or packed-f32
+// instruction every ~4.3 (tools/calib_valu2.hip), with the scalar unit running beside; the kernel is bound by exactly
+// that.  Hence: per-axis position updates as v_add / v_sub under an EXEC mask (the lane set of the axis' compare)
+// instead of v_cndmask-selected increments; plain instead of packed multiplies; the iteration cap from the carry of a
+// biased counter; ST_HIT written once behind the loop; no pushed-levels mask.
 #pragma once
 #include "svo_trav2.h"
 #include "svo_travloop.h"
 
 namespace svo {
 
-// SVO_DESC_LOAD_EARLY=1: the descending lanes' load leaves inside the descend section (more instructions between the
-// load and its use) and the popping lanes issue a second one; 0: one load per trip for both.
-// SVO_EXEC_STEPS=1: the per-axis position updates of a descend / an advance are subtractions under an EXEC mask (the lane
-// set of the axis' compare) instead of v_cndmask-selected increments added to every lane: v_cndmask (like every compare,
-// min / max, bit-field, shift-add and packed-f32 instruction) issues at half the rate of v_add / v_sub / logic ops on gfx950
-// (tools/calib_valu2.hip: 4.2 against 2.4 cycles per wave64 instruction), the scalar unit runs beside the vector ALU.
-#ifndef SVO_STACK_CLEAR
-#define SVO_STACK_CLEAR 1
-#endif
-#ifndef SVO_CAP_CARRY
-#define SVO_CAP_CARRY 1
-#endif
-#ifndef SVO_HIT_LATE
-#define SVO_HIT_LATE 1
-#endif
-#ifndef SVO_BIT_SHR
-#define SVO_BIT_SHR 1
-#endif
-#ifndef SVO_NO_PK
-#define SVO_NO_PK 1
-#endif
-#ifndef SVO_EXEC_STEPS
-#define SVO_EXEC_STEPS 1
-#endif
+// SVO_DESC_LOAD_EARLY=0: one load per trip, at its end, for the lanes that descended or popped; 1: the descending lanes'
+// load leaves as soon as their child's descriptor offset is known (20 instructions earlier), the popping lanes' at the end
 #ifndef SVO_DESC_LOAD_EARLY
 #define SVO_DESC_LOAD_EARLY 0
 #endif
@@ -134,14 +121,10 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
 #endif
   uint32_t t0, t1, t2, t3, bit;
   float tcx, tcm;
-#if SVO_CAP_CARRY
   r.iter += 0u - (kMaxIter + 1u);
-#endif
   asm volatile(
       "s_mov_b64 %[sv], exec\n\t"
-#if SVO_HIT_LATE
       "s_mov_b64 %[sm], %[act]\n"
-#endif
       "Ltrip%=:\n\t"
       "s_mov_b64 exec, %[act]\n\t"
       SVO_COUNT("c0", "c1", "exec")
@@ -155,34 +138,18 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"
       "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n\t"                  // idx = x | y << 1 | z << 2
       "v_xor_b32 %[cs], %[t0], %[oct]\n\t"                        // cs = idx ^ octant
-#if SVO_CAP_CARRY
       "v_add_co_u32 %[iter], vcc, 1, %[iter]\n\t"                 // iter++ on a counter biased by 2^32 - 1501: the carry is "iter > 1500"
-#else
-      "v_add_u32 %[iter], 1, %[iter]\n\t"                         // iter++
-      "v_cmp_lt_u32 vcc, 0x5dc, %[iter]\n\t"                      // iter > 1500
-#endif
-#if !SVO_BIT_SHR
-      "v_lshlrev_b32_e64 %[bit], %[cs], %[k101]\n\t"              // bit cs of the ne byte and of the has byte
-#endif
       "s_cmp_lg_u64 vcc, 0\n\t"
       "s_cbranch_scc1 Lcap%=\n"                                   // rare, out of line
       "Lnocap%=:\n\t"
       // ---- exit distances of the current cell (svotrace.comp:268-269)
       "v_mul_f32 %[tcx], %[px], %[cx]\n\t"
-#if SVO_NO_PK
       "v_mul_f32 v60, v56, %[cy]\n\t"
       "v_mul_f32 v61, v57, %[cz]\n\t"
-#else
-      "v_pk_mul_f32 v[60:61], v[56:57], %[cyz]\n\t"
-#endif
       "v_cmp_lt_f32 vcc, %[k005], %[tmin]\n\t"                    // t_min > 0.05 ...
       "v_sub_f32 %[tcx], %[tcx], %[bx]\n\t"
-#if SVO_NO_PK
       "v_sub_f32 v60, v60, %[by]\n\t"
       "v_sub_f32 v61, v61, %[bz]\n\t"
-#else
-      "v_pk_add_f32 v[60:61], v[60:61], %[byz] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-#endif
       "s_and_b64 vcc, vcc, %[conem]\n\t"                          // ... on a cone (secondary) ray: LOD 11 from here on (sticky)
       "v_cmp_le_f32_e64 %[sa], %[tmin], %[tmax]\n\t"              // t_min <= t_max
       "v_min3_f32 %[tcm], %[tcx], v60, v61\n\t"                   // tc_max
@@ -195,19 +162,9 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_andn2_b64 %[sd], %[sc], %[sb]\n\t"
       "s_and_b64 %[sd], %[sd], %[sa]\n\t"                         // in range & !at LOD & inside: descends if it has a child block
       // the ADVANCE step of every active lane, while the descriptor of lanes that descended / popped is in flight
-#if SVO_EXEC_STEPS
       "v_cmp_le_f32_e64 %[sx], %[tcx], %[tcm]\n\t"                // the axes whose exit distance is the cell's
       "v_cmp_le_f32_e64 %[sg], v60, %[tcm]\n\t"
       "v_cmp_le_f32_e64 %[sh], v61, %[tcm]\n\t"
-#else
-      "v_cmp_le_f32 vcc, %[tcx], %[tcm]\n\t"
-      "v_cmp_le_f32_e64 %[sg], v60, %[tcm]\n\t"
-      "v_cmp_le_f32_e64 %[sh], v61, %[tcm]\n\t"
-      "v_cndmask_b32_e64 %[t0], 0, v58, vcc\n\t"                  // per-axis decrement: the cell size or 0
-      "v_cndmask_b32_e64 v62, 0, v58, %[sg]\n\t"
-      "v_cndmask_b32_e64 v63, 0, v58, %[sh]\n\t"
-      "s_mov_b64 %[sx], vcc\n\t"
-#endif
       // an axis that steps out of the lower half leaves the parent: POP (svotrace.comp:341; idx & step after the flip =
       // step & ~idx before it) -- on lane sets, no step mask in a register
       "s_andn2_b64 %[sp], %[sx], %[six]\n\t"
@@ -216,12 +173,8 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_andn2_b64 %[sf], %[sh], %[siz]\n\t"
       "s_or_b64 %[sp], %[sp], %[sf]\n\t"
       "s_waitcnt vmcnt(0)\n\t"
-#if SVO_BIT_SHR
       "v_lshrrev_b32 %[bit], %[cs], v65\n\t"            // bit cs of the ne byte -> bit 0, of the has byte -> bit 8
       "v_and_b32 %[bit], %[k101], %[bit]\n\t"
-#else
-      "v_and_b32 %[bit], %[bit], v65\n\t"
-#endif
       "v_cmp_ne_u32_sdwa %[sa], %[bit], %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // child not empty
       "v_cmp_ne_u32_sdwa vcc, %[bit], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"     // child has a child block
       // lane sets
@@ -231,10 +184,6 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_andn2_b64 %[sa], exec, %[se]\n\t"                // ADVANCE = the rest
       "s_and_b64 %[sp], %[sp], %[sa]\n\t"                 // POP = the advancing lanes that leave their parent
       "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = not empty & in range & (at LOD | (inside & no child block))
-#if !SVO_HIT_LATE
-      "s_mov_b64 exec, %[se]\n\t"
-      "v_mov_b32 %[st], 2\n\t"                            // ST_HIT
-#endif
       "s_andn2_b64 %[act], %[act], %[se]\n\t"
       // ---- DESCEND (svotrace.comp:291-327)
       "s_mov_b64 exec, %[sd]\n\t"
@@ -247,9 +196,6 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_and_saveexec_b64 %[sb], vcc\n\t"
       "v_lshl_add_u32 v63, %[t1], 9, %[lds8]\n\t"
       "ds_write2_b32 v63, %[self], %[tmax] offset1:1\n\t" // {parent state, t_max}
-#if !SVO_STACK_CLEAR
-      "v_lshl_or_b32 %[wr], 1, %[t1], %[wr]\n\t"
-#endif
       "s_mov_b64 exec, %[sd]\n\t"
       "v_bfm_b32 %[t1], %[cs], 8\n\t"                     // the has bits of the children below cs
       "v_and_b32 %[t1], %[t1], v65\n\t"
@@ -257,25 +203,16 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_lshl_add_u32 %[self], %[t1], 3, v64\n\t"         // the child's descriptor
       SVO_DESC_LOAD_D
       "v_mul_f32 %[t0], %[cx], v58\n\t"
-#if SVO_NO_PK
       "v_mul_f32 v62, %[cy], v58\n\t"
       "v_mul_f32 v63, %[cz], v58\n\t"
-#else
-      "v_pk_mul_f32 v[62:63], %[cyz], v[58:59] op_sel_hi:[1,0]\n\t"
-#endif
       "v_add_f32 %[t0], %[t0], %[tcx]\n\t"                // centre distances
-#if SVO_NO_PK
       "v_add_f32 v62, v62, v60\n\t"
       "v_add_f32 v63, v63, v61\n\t"
-#else
-      "v_pk_add_f32 v[62:63], v[62:63], v[60:61]\n\t"
-#endif
       "v_cmp_gt_f32 vcc, %[t0], %[tmin]\n\t"
       "v_cmp_gt_f32_e64 %[sb], v62, %[tmin]\n\t"
       "v_cmp_gt_f32_e64 %[sc], v63, %[tmin]\n\t"
       "v_add_u32 %[scale], -1, %[scale]\n\t"
       "v_mov_b32 %[h], %[tcm]\n\t"                        // h = tc_max
-#if SVO_EXEC_STEPS
       "v_mov_b32 %[tmax], %[t3]\n\t"                     // t_max = tv_max
       "s_and_b64 exec, %[sd], vcc\n\t"                   // the upper half on an axis: position += half, under the compare's lane set
       "v_add_f32 %[px], %[px], v58\n\t"
@@ -283,36 +220,22 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_add_f32 v56, v56, v58\n\t"
       "s_and_b64 exec, %[sd], %[sc]\n\t"
       "v_add_f32 v57, v57, v58\n"
-#else
-      "v_cndmask_b32_e64 %[t0], 0, v58, vcc\n\t"
-      "v_cndmask_b32_e64 v62, 0, v58, %[sb]\n\t"
-      "v_cndmask_b32_e64 v63, 0, v58, %[sc]\n\t"
-      "v_add_f32 %[px], %[px], %[t0]\n\t"
-      "v_pk_add_f32 v[56:57], v[56:57], v[62:63]\n\t"
-      "v_mov_b32 %[tmax], %[t3]\n"                        // t_max = tv_max
-#endif
       "LnoD%=:\n\t"
       // ---- ADVANCE (svotrace.comp:329-339)
       "s_mov_b64 exec, %[sa]\n\t"
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c4", "c5", "exec")
       "v_mov_b32 %[tmin], %[tcm]\n\t"                     // t_min = tc_max
-#if SVO_EXEC_STEPS
       "s_and_b64 exec, %[sa], %[sx]\n\t"                  // step: position -= cell size on the axes that leave the cell
       "v_sub_f32 %[px], %[px], v58\n\t"
       "s_and_b64 exec, %[sa], %[sg]\n\t"
       "v_sub_f32 v56, v56, v58\n\t"
       "s_and_b64 exec, %[sa], %[sh]\n\t"
       "v_sub_f32 v57, v57, v58\n\t"
-#else
-      "v_sub_f32 %[px], %[px], %[t0]\n\t"
-      "v_pk_add_f32 v[56:57], v[56:57], v[62:63] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-#endif
       "s_mov_b64 exec, %[sp]\n\t"                         // left the parent: POP
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
-#if SVO_EXEC_STEPS
       // differing bits of the position before (= after + cell size, exact) and after the step, on the axes that stepped
       "v_mov_b32 %[t0], 1\n\t"                            // (| 1 keeps ffbh defined)
       "s_and_b64 exec, %[sp], %[sx]\n\t"
@@ -325,27 +248,14 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_add_f32 %[t1], v57, v58\n\t"
       "v_bitop3_b32 %[t0], %[t0], %[t1], v57 bitop3:0xf6\n\t"
       "s_mov_b64 exec, %[sp]\n\t"
-#else
-      "v_add_f32 %[t0], %[px], %[t0]\n\t"                 // position before the step (exact)
-      "v_pk_add_f32 v[62:63], v[56:57], v[62:63]\n\t"
-      "v_xor_b32 %[t0], %[t0], %[px]\n\t"
-      "v_xor_b32 %[t1], v62, v56\n\t"
-      "v_bitop3_b32 %[t0], %[t0], v63, v57 bitop3:0xf6\n\t"   // a | (b ^ c)
-      "v_or3_b32 %[t0], %[t0], %[t1], 1\n\t"              // differing bits (| 1 keeps ffbh defined)
-#endif
       "v_ffbh_u32 %[t0], %[t0]\n\t"
       "v_sub_u32 %[t2], 20, %[t0]\n\t"                    // scale - 11
       "v_xor_b32 %[scale], 31, %[t0]\n\t"                 // scale = 31 - leading zeros
       "v_min_u32 %[t1], 11, %[t2]\n\t"
       "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"     // cell size = 2^(scale - 23)
       "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
-#if SVO_STACK_CLEAR
       "ds_read_b32 %[self], %[t0]\n\t"                    // a level this ray never pushed holds the zeros it started on:
       "ds_read_b32 %[tmax], %[t0] offset:4\n\t"           // state (0, 0) = descriptor 0, t_max 0
-#else
-      "ds_read2_b32 v[62:63], %[t0] offset1:1\n\t"
-      "v_bfe_i32 %[t2], %[wr], %[t2], 1\n\t"              // all ones if this ray pushed that level
-#endif
       "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
       "v_mov_b32 %[h], 0\n\t"                             // h = 0
       "v_and_b32 %[px], %[px], %[t3]\n\t"                 // round the position to the cell
@@ -353,10 +263,6 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_and_b32 v57, v57, %[t3]\n\t"
       "v_cmp_le_u32 vcc, 23, %[scale]\n\t"                // left the octree: MISS
       "s_waitcnt lgkmcnt(0)\n\t"
-#if !SVO_STACK_CLEAR
-      "v_and_b32 %[self], %[t2], v62\n\t"                 // never pushed: state (0, 0) = descriptor 0, t_max 0
-      "v_and_b32 %[tmax], %[t2], v63\n\t"
-#endif
       "s_cmp_lg_u64 vcc, 0\n\t"
       "s_cbranch_scc1 Lmiss%=\n"                          // out of line
       "LnoA%=:\n\t"
@@ -370,32 +276,23 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_mov_b64 exec, vcc\n\t"
       "v_mov_b32 %[st], 4\n\t"
       "s_andn2_b64 %[act], %[act], vcc\n\t"
-#if SVO_HIT_LATE
       "s_andn2_b64 %[sm], %[sm], vcc\n\t"
-#endif
       "s_mov_b64 exec, %[act]\n\t"
       "s_branch Lnocap%=\n"
       "Lmiss%=:\n\t"                                      // left the octree: status = ST_MISS
       "s_mov_b64 exec, vcc\n\t"
       "v_mov_b32 %[st], 3\n\t"
       "s_andn2_b64 %[act], %[act], vcc\n\t"
-#if SVO_HIT_LATE
       "s_andn2_b64 %[sm], %[sm], vcc\n\t"
-#endif
       "s_andn2_b64 %[sp], %[sp], vcc\n\t"
       "s_branch LnoA%=\n"
       "Lend%=:\n\t"
-#if SVO_HIT_LATE
       "s_andn2_b64 exec, %[sm], %[act]\n\t"             // the lanes that stopped without leaving the octree or the budget: ST_HIT
       "v_mov_b32 %[st], 2\n\t"
-#endif
       "s_waitcnt vmcnt(0)\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
       : [px] "+v"(r.px), "+{v[56:57]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v58}"(r.sexp), [h] "+v"(r.h),
         [scale] "+v"(r.scale), [cs] "+v"(r.cs), [self] "+v"(r.self), "+{v64}"(r.dlo), "+{v65}"(r.dhi),
-#if !SVO_STACK_CLEAR
-        [wr] "+v"(r.written),
-#endif
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
         [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
@@ -404,15 +301,10 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
         , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
 #endif
       : [cx] "v"(r.cx), [bx] "v"(r.bx),
-#if !SVO_NO_PK
-        [cyz] "v"(r.cyz), [byz] "v"(r.byz),
-#endif
         [cy] "v"(r.cyz.x), [cz] "v"(r.cyz.y), [by] "v"(r.byz.x), [bz] "v"(r.byz.y), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
         [lds8] "v"(lds8), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
-      : "vcc", "scc", "memory", "v59", "v60", "v61", "v62", "v63");
-#if SVO_CAP_CARRY
+      : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
   r.iter += kMaxIter + 1u;
-#endif
 #ifdef SVO_STAMPS
   mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7;
 #endif
