@@ -178,6 +178,12 @@ int svo_set_derived(svo_ctx *ctx, int mode);
 /* builds the table if the pool changed; *descriptors = its entries, *bytes = device memory it holds, *walkable = 1 if
  * pipeline 1 walks it (0 = the pool is not derivable), *build_ms = GPU time of the last build.  Any may be NULL. */
 int svo_derived_info(svo_ctx *ctx, uint64_t *descriptors, uint64_t *bytes, int *walkable, float *build_ms);
+/* svo_pool_update (Renderer.updateSSBO of an SDF brush stroke's two byte ranges, Main.java:349-350) does not drop a
+ * walkable table: the states whose child block the range touches are recomputed, changed sibling groups and new
+ * subtrees are appended at the table's end (SVO_DERIVED_REFRESH=0 in the environment: rebuild instead).  *refreshes =
+ * updates followed that way so far, and of the last one: *states recomputed, *added descriptors, GPU
+ * time.  Any may be NULL. */
+int svo_derived_refresh_info(svo_ctx *ctx, uint64_t *refreshes, uint64_t *states, uint64_t *added, float *gpu_ms);
 /* record per-pixel svo_hit (costs 16 B/pixel of stores); default on */
 int svo_set_hit_records(svo_ctx *ctx, int enabled);
 

@@ -251,6 +251,10 @@ int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
 }
 
 int svo_pool_update(svo_ctx *c, const void *host_base, uint64_t start, uint64_t end) {
+  // a walkable descriptor table follows a ranged update instead of being rebuilt (derive::refresh_table): an SDF brush
+  // stroke is two such updates (Main.java:349-350), the table of the 8192^3 scene takes 6.7 ms to build
+  static const bool follow = []() { const char *e = getenv("SVO_DERIVED_REFRESH"); return !(e && e[0] == '0'); }();
+  const bool had_table = c && follow && c->derived_valid && c->dt.ok;
   if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || !host_base) return fail(c, SVO_E_INVALID, "svo_pool_update: null buffer");
   if (start >= end) return fail(c, SVO_E_INVALID, "Update SSBO error: Invalid parameters.");
@@ -263,7 +267,13 @@ int svo_pool_update(svo_ctx *c, const void *host_base, uint64_t start, uint64_t 
   }
   HIPCHK(c, hipMemcpy(c->d_pool + start, (const uint8_t *)host_base + start, end - start, hipMemcpyHostToDevice));
   if (end > c->pool_len) c->pool_len = end;
-  if (start < 4) return refresh_dword0(c);
+  if (start < 4) { int rc = refresh_dword0(c); if (rc) return rc; }
+  if (had_table) {
+    bool refreshed = false;
+    hipError_t e = derive::refresh_table(c->dt, c->d_pool, c->pool_len, start, end, c->own_stream, &refreshed);
+    if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("descriptor table refresh: ") + hipGetErrorString(e));
+    c->derived_valid = refreshed;   // false: the next dispatch builds it anew
+  }
   return SVO_OK;
 }
 
@@ -477,6 +487,15 @@ int svo_derived_info(svo_ctx *c, uint64_t *descriptors, uint64_t *bytes, int *wa
   if (bytes) *bytes = (uint64_t)c->dt.cap * 2 * sizeof(uint2);
   if (walkable) *walkable = c->dt.ok ? 1 : 0;
   if (build_ms) *build_ms = c->dt.build_ms;
+  return SVO_OK;
+}
+
+int svo_derived_refresh_info(svo_ctx *c, uint64_t *refreshes, uint64_t *states, uint64_t *added, float *gpu_ms) {
+  if (!c) return SVO_E_INVALID;
+  if (refreshes) *refreshes = c->dt.refreshes;
+  if (states) *states = c->dt.refresh_states;
+  if (added) *added = c->dt.refresh_added;
+  if (gpu_ms) *gpu_ms = c->dt.refresh_ms;
   return SVO_OK;
 }
 

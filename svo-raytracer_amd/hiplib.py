@@ -17,7 +17,7 @@ EXPORTS = [
     "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_build_from_voxels", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
     "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_set_batch", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel", "svo_read_beam",
-    "svo_output_device_ptrs", "svo_set_derived", "svo_derived_info",
+    "svo_output_device_ptrs", "svo_set_derived", "svo_derived_info", "svo_derived_refresh_info",
     "svo_ring_create", "svo_ring_destroy", "svo_ring_submit", "svo_ring_wait", "svo_ring_query", "svo_ring_read_color",
     "svo_ring_read_depth", "svo_ring_read_hits", "svo_ring_read_pixel", "svo_ring_bind_slot", "svo_ring_device_ptrs",
     "svo_set_reserved_cus", "svo_pool_commit", "svo_ring_forward_slot", "svo_dev_alloc", "svo_dev_free", "svo_dev_read",
@@ -100,6 +100,7 @@ def lib(path=None):
                                            ctypes.POINTER(u64), ctypes.POINTER(vp)]
         L.svo_set_derived.argtypes = [vp, ci]
         L.svo_derived_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ci), fp]
+        L.svo_derived_refresh_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), fp]
         L.svo_dispatch.argtypes = [vp]
         L.svo_dispatch_async.argtypes = [vp]
         L.svo_sync.argtypes = [vp]
@@ -239,6 +240,13 @@ class HipContext:
         n, b, w, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int(), ctypes.c_float()
         self._chk(self._L.svo_derived_info(self._h, ctypes.byref(n), ctypes.byref(b), ctypes.byref(w), ctypes.byref(ms)))
         return {"descriptors": int(n.value), "bytes": int(b.value), "walkable": bool(w.value), "build_ms": float(ms.value)}
+
+    def derived_refresh_info(self):
+        """what svo_pool_update did to the table: updates followed without a rebuild; states recomputed, descriptors appended
+        and GPU ms of the last one"""
+        r, n, a, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_float()
+        self._chk(self._L.svo_derived_refresh_info(self._h, ctypes.byref(r), ctypes.byref(n), ctypes.byref(a), ctypes.byref(ms)))
+        return {"refreshes": int(r.value), "states": int(n.value), "added": int(a.value), "gpu_ms": float(ms.value)}
 
     def set_batch(self, nframes, frame_stride=0):
         self._chk(self._L.svo_set_batch(self._h, int(nframes), int(frame_stride)))

@@ -102,3 +102,68 @@ def test_ranged_updates_render_like_a_full_upload(pipeline):
             assert (ctx.pool_download(host.size) == host).all()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_descriptor_table_follows_brush_strokes_without_a_rebuild():
+    """svo_pool_update keeps a walkable descriptor table up to date (derive::refresh_table: states whose child block a
+    range touches are recomputed, changed sibling groups and new subtrees appended) instead of dropping it: a sequence
+    of brush strokes -- fills that re-tag interior nodes, carves, strokes over earlier strokes -- must render exactly like
+    the oracle after every stroke, on the table, and the table must not have been rebuilt in between."""
+    from svo_raytracer_amd import hiplib
+    from oracle import oracle
+    n, lod = 128, 7
+    pool, _ = scene.build_scene(n)
+    o = hostlib.Octree(1 << 16)
+    o.adopt(pool)
+    rng = np.random.default_rng(11)
+    cams = [KEDIT, CAMERAS["K1"]]
+    ctx = hiplib.HipContext(0)
+    try:
+        ctx.set_pipeline(1)
+        ctx.set_derived(1)
+        ctx.pool_upload(pool)
+        info = ctx.derived_info()
+        assert info["walkable"]
+        followed = issued = 0
+        prev_host = pool
+        for stroke in range(14):
+            org = tuple(int(v) for v in rng.integers(n // 4, 3 * n // 4, 3))
+            r = int(rng.integers(3, 14))
+            val = int(rng.choice([0, 0, 1, 2, 3]))
+            if stroke % 5 == 4:
+                cb = restated.useSDFBrushBox(o, org, r, max(2, r // 2), r, val, worldSize=n, maxLOD=lod)
+            else:
+                cb = restated.useSDFBrushSphere(o, org, r, val, worldSize=n, maxLOD=lod)
+            host = o.getByteBuffer()
+            before = ctx.derived_refresh_info()["refreshes"]
+            # (a stroke that rewrites the root record -- its mask changes when one of the eight top-level children is
+            # re-tagged, common in a 128^3 world, out of reach of a brush at 8192^3 -- is the one case left to a rebuild)
+            root_changed = bool((host[1:7] != prev_host[1:7]).any())
+            n_updates = 0
+            if cb[1] > cb[0]:
+                ctx.pool_update(host, cb[0], cb[1]); n_updates += 1
+            if cb[3] > cb[2]:
+                ctx.pool_update(host, cb[2], cb[3]); n_updates += 1
+            prev_host = host
+            after = ctx.derived_refresh_info()
+            followed += after["refreshes"] - before
+            if not root_changed:
+                issued += n_updates
+                assert after["refreshes"] - before == n_updates, (stroke, cb)
+            for cam in cams:
+                got = ctx.render(None, 128, 80, cam, 2 + stroke, 0)
+                ref = oracle.render(host, 128, 80, cam, 2 + stroke, 0)
+                assert (got["rgba"] == ref["rgba"]).all(), stroke
+                assert (got["depth"].view(np.uint32) == ref["depth"].view(np.uint32)).all(), stroke
+                for k in ("pointer", "value", "raw_normal", "level", "iter"):
+                    assert (got["hits"][k] == ref["hits"][k]).all(), (stroke, k)
+            assert ctx.derived_info()["walkable"]
+        assert issued >= 10 and followed >= issued, (followed, issued)   # none of those fell back to a rebuild
+        # the same pool uploaded whole into a fresh table renders the same bytes (and has no garbage groups)
+        grown = ctx.derived_info()["descriptors"]
+        ctx.pool_upload(o.getByteBuffer())
+        fresh = ctx.derived_info()["descriptors"]
+        assert fresh <= grown
+    finally:
+        ctx.close()
