@@ -146,3 +146,90 @@ def test_table_follows_ranged_pool_updates(ctx):
     ref = oracle.render(b, 160, 96, CAMERAS["K1"], 2, 0)
     bad = _same(res, ref)
     assert bad == {k: 0 for k in bad}, bad
+
+
+def _reachable_records(pool):
+    """(offset, tag) of every record a proper walk from the root reaches"""
+    out, stack = [], [0]
+    while stack:
+        p = stack.pop()
+        cp = int.from_bytes(bytes(pool[p + 1:p + 5]), "big", signed=True)
+        if cp == 0:
+            continue
+        mask = (int(pool[p + 5]) << 8) | int(pool[p + 6])
+        c = p + cp
+        for k in range(8):
+            tag = (mask >> (2 * k)) & 3
+            out.append((c, tag))
+            if tag == 0:
+                stack.append(c)
+            c += {0: 7, 1: 3, 2: 7, 3: 1}[tag]
+    return out
+
+
+def test_refreshed_table_equals_a_rebuilt_one_under_random_record_edits(ctx):
+    """derive::refresh_table against the full build: forty small edits of a kind no brush makes -- value bytes zeroed
+    and set, child pointers cut and re-pointed at other blocks (shared and cyclic subtrees), tag masks rewritten,
+    records copied over one another -- each sent through svo_pool_update.  After every edit the context whose table
+    followed the update renders what a context that was given the whole pool anew renders, on the table and on the
+    records, bit for bit (whether or not the edited pool is still walkable), and now and then what the oracle renders."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    from oracle import oracle
+    pool, _ = scene.build_scene(64)
+    host = pool.copy()
+    recs = _reachable_records(host)
+    inner = [o for o, t in recs if t == 0 and int.from_bytes(bytes(host[o + 1:o + 5]), "big") != 0]
+    rng = np.random.default_rng(23)
+    fresh = hiplib.HipContext(0)
+    try:
+        fresh.set_pipeline(1)
+        ctx.set_derived(1)
+        ctx.pool_upload(host)
+        assert ctx.derived_info()["walkable"]
+        followed = 0
+        for edit in range(40):
+            kind = edit % 5
+            o, tag = recs[int(rng.integers(len(recs)))]
+            if kind == 0:      # a value byte flips between empty and solid
+                lo, hi = o, o + 1
+                host[o] = 0 if host[o] else 3
+            elif kind == 1:    # an interior node loses its children
+                o = inner[int(rng.integers(len(inner)))]
+                lo, hi = o + 1, o + 5
+                host[lo:hi] = 0
+            elif kind == 2:    # ... or gets another node's: a shared (possibly cyclic) subtree
+                o, src = inner[int(rng.integers(len(inner)))], inner[int(rng.integers(len(inner)))]
+                tgt = src + int.from_bytes(bytes(host[src + 1:src + 5]), "big", signed=True)
+                lo, hi = o + 1, o + 7
+                host[o + 1:o + 5] = np.frombuffer(int(tgt - o).to_bytes(4, "big", signed=True), np.uint8)
+                host[o + 5:o + 7] = host[src + 5:src + 7]
+            elif kind == 3:    # a tag mask is rewritten: the children's records are re-read at other sizes
+                o = inner[int(rng.integers(len(inner)))]
+                lo, hi = o + 5, o + 7
+                host[lo:hi] = rng.integers(0, 256, 2, dtype=np.uint8)
+            else:              # seven bytes of one record land on another
+                src = recs[int(rng.integers(len(recs)))][0]
+                lo, hi = o, min(o + 7, host.size)
+                host[lo:hi] = host[src:src + (hi - lo)].copy()
+            if lo < 7:
+                continue       # (the root record: a rebuild by design, covered elsewhere)
+            before = ctx.derived_refresh_info()["refreshes"]
+            ctx.pool_update(host, lo, hi)
+            followed += ctx.derived_refresh_info()["refreshes"] - before
+            for derived in (1, 0):
+                ctx.set_derived(derived)
+                fresh.set_derived(derived)
+                a = ctx.render(None, 128, 80, CAMERAS["K1"], 3 + edit, 0)
+                b = fresh.render(host, 128, 80, CAMERAS["K1"], 3 + edit, 0)
+                bad = _same(a, b)
+                assert bad == {k: 0 for k in bad}, (edit, kind, derived, bad)
+            ctx.set_derived(1)
+            if edit % 8 == 7:
+                ref = oracle.render(host, 128, 80, CAMERAS["K1"], 3 + edit, 0)
+                bad = _same(a, ref)
+                assert bad == {k: 0 for k in bad}, (edit, bad)
+        assert followed >= 10, followed
+    finally:
+        fresh.close()
