@@ -85,6 +85,9 @@ jint Java_src_engine_HipRenderer_nCountFrame(void *env, void *cls, jlong ctx, jl
 jint Java_src_engine_HipRenderer_nGetStats(void *env, void *cls, jlong ctx, jlong stats_addr);
 /* svo_derived_info: descriptors of the table, or a negative status; *walkable_addr (4 bytes, may be 0) = 1 if walked */
 jlong Java_src_engine_HipRenderer_nDerivedInfo(void *env, void *cls, jlong ctx, jlong walkable_addr);
+/* svo_derived_refresh_info: ranged updates (Renderer.updateSSBO) the descriptor table followed without a rebuild so far;
+ * states recomputed / descriptors appended by the last one through the two addresses (0 = not wanted) */
+jlong Java_src_engine_HipRenderer_nDerivedRefreshInfo(void *env, void *cls, jlong ctx, jlong states_addr, jlong added_addr);
 /* ---- frames in flight (svo_ring_*): what a Java host cannot own -- streams, device buffers -- stays in the library */
 jint Java_src_engine_HipRenderer_nRingCreate(void *env, void *cls, jlong ctx, jint slots, jint frames_per_slot, jint want_hits);
 jint Java_src_engine_HipRenderer_nRingDestroy(void *env, void *cls, jlong ctx);

@@ -261,6 +261,12 @@ public class HipRenderer {
     check(nSetPipeline(ctx, pipeline));
   }
 
+  /** How many updateSSBO ranges the library's descriptor table has followed in place (an SDF stroke is two; a stroke
+   *  that rewrites the root record makes the next dispatch rebuild the table instead). */
+  public long tableRefreshes() {
+    return nDerivedRefreshInfo(ctx, 0L, 0L);
+  }
+
   /** Multi-GPU split by interleaved 8-pixel tile rows (one HipRenderer context per GPU). */
   public void setStripes(int firstTileRow, int tileRowStep, int nTileRows, int outRow0) {
     check(nSetStripes(ctx, firstTileRow, tileRowStep, nTileRows, outRow0));
@@ -305,6 +311,7 @@ public class HipRenderer {
   private static native int nCountFrame(long ctx, long statsAddr);
   private static native int nGetStats(long ctx, long statsAddr);
   private static native long nDerivedInfo(long ctx, long walkableAddr);
+  private static native long nDerivedRefreshInfo(long ctx, long statesAddr, long addedAddr);
   private static native int nRingCreate(long ctx, int slots, int framesPerSlot, int wantHits);
   private static native int nRingDestroy(long ctx);
   private static native int nRingSubmit(long ctx, int frameNumber, int nframes);

@@ -108,6 +108,11 @@ jlong Java_src_engine_HipRenderer_nDerivedInfo(void *, void *, jlong ctx, jlong 
   const int rc = svo_derived_info(CTX(ctx), &n, nullptr, (int *)(intptr_t)walkable_addr, nullptr);
   return rc == SVO_OK ? (jlong)n : (jlong)rc;
 }
+jlong Java_src_engine_HipRenderer_nDerivedRefreshInfo(void *, void *, jlong ctx, jlong states_addr, jlong added_addr) {
+  uint64_t n = 0;
+  const int rc = svo_derived_refresh_info(CTX(ctx), &n, (uint64_t *)(intptr_t)states_addr, (uint64_t *)(intptr_t)added_addr, nullptr);
+  return rc == SVO_OK ? (jlong)n : (jlong)rc;
+}
 jint Java_src_engine_HipRenderer_nRingCreate(void *, void *, jlong ctx, jint slots, jint frames_per_slot, jint want_hits) {
   return svo_ring_create(CTX(ctx), slots, frames_per_slot, want_hits);
 }

@@ -63,6 +63,8 @@ def test_jni_shim_called_with_jni_typed_arguments(ctx):
     nBuildFromHeightmap = fn("nBuildFromHeightmap", jlong, jlong, jlong, jlong, jint)
     nBuildFromVoxels = fn("nBuildFromVoxels", jlong, jlong, jlong, jint)
     nSetProgressive = fn("nSetProgressive", jint, jlong, jint)
+    nDerivedRefreshInfo = fn("nDerivedRefreshInfo", jlong, jlong, jlong, jlong)
+    nSetPipeline = fn("nSetPipeline", jint, jlong, jint)
 
     pool, _ = scene.build_scene(128)
     cam = np.asarray(CAMERAS["K1"], dtype=np.float32)
@@ -84,6 +86,7 @@ def test_jni_shim_called_with_jni_typed_arguments(ctx):
         assert nSetCamera(j, *[float(v) for v in cam]) == 0
         assert nSetParams(j, 3, 0, int(pool.size), 0, 2, 0, 1) == 0
         assert nResize(j, w, h) == 0
+        assert nSetPipeline(j, 1) == 0            # persistent waves on the descriptor table (HipRenderer's choice)
         assert nDispatch(j) == 0
         rgba = np.zeros((h, w, 4), dtype=np.uint8)
         depth = np.zeros((h, w), dtype=np.float32)
@@ -106,6 +109,8 @@ def test_jni_shim_called_with_jni_typed_arguments(ctx):
         edited[ptrs] = 2
         lo, hi = int(ptrs.min()), int(ptrs.max()) + 1
         assert nPoolUpdate(j, edited.ctypes.data, lo, hi) == 0
+        n_states = ctypes.c_uint64(0)
+        assert nDerivedRefreshInfo(j, ctypes.addressof(n_states), 0) == 1 and n_states.value >= 1   # the table followed the update
         assert nPoolUpdate(j, edited.ctypes.data, 10, 10) != 0          # start >= end: rejected like the reference
         assert nPoolUpdate(j, edited.ctypes.data, -1, 5) != 0
         back = np.zeros(pool.size, dtype=np.uint8)
