@@ -146,7 +146,7 @@ int svo_set_rows(svo_ctx *ctx, int y0, int y1);
 int svo_set_stripes(svo_ctx *ctx, int first_tile_row, int tile_row_step, int n_tile_rows, int out_row0);
 /* 0 = one thread per pixel (the reference's decomposition); 1 = persistent waves with lane
  * refill and in-place bounce regeneration; 2 = stage-per-kernel wavefront tracing with
- * compacted ray queues.  All three produce identical bytes. */
+ * compacted ray queues.  All three produce identical bytes; a new context runs pipeline 1 (the fast one). */
 int svo_set_pipeline(svo_ctx *ctx, int pipeline);
 /* pipeline-1 launch shape: persistent waves per CU (0 = fill the GPU: right for one frame at a time;
  * about 10 when the caller keeps 2-3 frames in flight on alternating streams) and the refill round

@@ -256,7 +256,7 @@ public class HipRenderer {
     check(nSetTuning(ctx, wavesPerCu, roundThresholdSixteenths));
   }
 
-  /** 0 one thread per pixel (the shader's decomposition), 1 persistent waves (fastest), 2 staged wavefront. */
+  /** 0 one thread per pixel (the shader's decomposition), 1 persistent waves (fastest; what a new context runs), 2 staged wavefront. */
   public void setPipeline(int pipeline) {
     check(nSetPipeline(ctx, pipeline));
   }

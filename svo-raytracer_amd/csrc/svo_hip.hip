@@ -40,7 +40,7 @@ struct svo_ctx {
   int batch = 1;                 // frames per dispatch (svo_set_batch)
   uint64_t frame_stride = 0;     // elements between consecutive frames of a batch in each output
   uint32_t mirror_mask = 0;
-  int pipeline = 0;
+  int pipeline = 1;        // persistent waves on the descriptor table; 0 / 2: svo_set_pipeline
   int write_hits = 1;
   // outputs
   uint32_t *d_color = nullptr;
