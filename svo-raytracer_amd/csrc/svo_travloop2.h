@@ -226,6 +226,9 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c4", "c5", "exec")
       "v_mov_b32 %[tmin], %[tcm]\n\t"                     // t_min = tc_max
+      "v_mov_b32 %[t0], %[px]\n\t"                        // the position before the step, for the POP's differing bits
+      "v_mov_b32 %[t1], v56\n\t"
+      "v_mov_b32 %[t2], v57\n\t"
       "s_and_b64 exec, %[sa], %[sx]\n\t"                  // step: position -= cell size on the axes that leave the cell
       "v_sub_f32 %[px], %[px], v58\n\t"
       "s_and_b64 exec, %[sa], %[sg]\n\t"
@@ -236,18 +239,11 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
-      // differing bits of the position before (= after + cell size, exact) and after the step, on the axes that stepped
-      "v_mov_b32 %[t0], 1\n\t"                            // (| 1 keeps ffbh defined)
-      "s_and_b64 exec, %[sp], %[sx]\n\t"
-      "v_add_f32 %[t1], %[px], v58\n\t"
-      "v_bitop3_b32 %[t0], %[t0], %[t1], %[px] bitop3:0xf6\n\t"   // a | (b ^ c)
-      "s_and_b64 exec, %[sp], %[sg]\n\t"
-      "v_add_f32 %[t1], v56, v58\n\t"
-      "v_bitop3_b32 %[t0], %[t0], %[t1], v56 bitop3:0xf6\n\t"
-      "s_and_b64 exec, %[sp], %[sh]\n\t"
-      "v_add_f32 %[t1], v57, v58\n\t"
-      "v_bitop3_b32 %[t0], %[t0], %[t1], v57 bitop3:0xf6\n\t"
-      "s_mov_b64 exec, %[sp]\n\t"
+      // differing bits of the position before and after the step
+      "v_xor_b32 %[t0], %[t0], %[px]\n\t"
+      "v_bitop3_b32 %[t0], %[t0], %[t1], v56 bitop3:0xf6\n\t"   // a | (b ^ c)
+      "v_bitop3_b32 %[t0], %[t0], %[t2], v57 bitop3:0xf6\n\t"
+      "v_or_b32 %[t0], 1, %[t0]\n\t"                      // (| 1 keeps ffbh defined)
       "v_ffbh_u32 %[t0], %[t0]\n\t"
       "v_sub_u32 %[t2], 20, %[t0]\n\t"                    // scale - 11
       "v_xor_b32 %[scale], 31, %[t0]\n\t"                 // scale = 31 - leading zeros
