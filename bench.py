@@ -393,7 +393,8 @@ def main(argv=None, ctx_factory=None):
         ctx.set_tuning(0, args.thresh)   # one frame at a time: fill the GPU
     ctx.set_batch(1, 0)
     ctx.set_params(first_timed, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
-    kernel_ms_isolated = float(np.mean(ctx.time_frames(2, max(5, min(args.steps, 30))))) if args.isolated else None
+    # (the median: one frame in a few hundred takes milliseconds longer on these boxes, and a mean over 20 would carry it)
+    kernel_ms_isolated = float(np.median(ctx.time_frames(2, max(5, min(args.steps, 30))))) if args.isolated else None
     out_bytes_px = 8 + (16 if args.hits else 0)
     my_alg = mine[2] + mine[3] * out_bytes_px
 
