@@ -26,7 +26,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("pixels", ctypes.c_uint64), ("rays", ctypes.c_uint64), ("nan_rays", ctypes.c_uint64),
                 ("iterations", ctypes.c_uint64), ("alg_bytes", ctypes.c_uint64), ("max_iter", ctypes.c_uint64), ("descends", ctypes.c_uint64),
                 ("advances", ctypes.c_uint64), ("pops", ctypes.c_uint64),
-                ("push_by_scale", ctypes.c_uint64 * 24), ("pop_by_scale", ctypes.c_uint64 * 24)]
+                ("push_by_scale", ctypes.c_uint64 * 24), ("pop_by_scale", ctypes.c_uint64 * 24),
+                ("cold_pops", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: (int(getattr(self, k)) if not hasattr(getattr(self, k), '__len__') else list(getattr(self, k)))

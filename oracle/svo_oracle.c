@@ -75,6 +75,9 @@ typedef struct svo_oracle_stats {
   uint64_t max_iter;   /* largest iteration count of a counted ray */
   uint64_t descends, advances, pops; /* iteration mix of counted rays (diagnostic) */
   uint64_t push_by_scale[24], pop_by_scale[24]; /* stack traffic per level (diagnostic) */
+  uint64_t cold_pops;  /* pops inside the octree that read a stack level their ray never pushed: the zero-initialised
+                          entry {node 0, t_max 0} is what the walk goes on with (diagnostic; finds cases for the tests of
+                          the HIP stack's zeroed column) */
 } svo_oracle_stats;
 
 typedef struct { float x, y, z; } vec3;
@@ -276,6 +279,7 @@ static inline int all_nan3(vec3 v) { return isnan(v.x) && isnan(v.y) && isnan(v.
 static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, int maxDepth, int coneTrace, float t_start) {
   stackEntry octstack[MAX_SCALE + 1];
   memset(octstack, 0, sizeof octstack);
+  uint32_t pushed = 0; /* diagnostic only (cold_pops) */
   res->debugColor = v3(0.3f, 0.3f, 0.6f);
   Node parent = extract_node(c, 0);
   uint32_t iter = 0;
@@ -346,6 +350,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
           if (!is_nan_ray) c->st->push_by_scale[scale]++;
           octstack[scale].node = parent;
           octstack[scale].tmax = t_max;
+          pushed |= 1u << scale;
         }
         h = tc_max;
         if (!is_nan_ray) c->st->descends++;
@@ -380,6 +385,7 @@ static int intersect_octree(ctx_t *c, vec3 origin, vec3 dir, castResult *res, in
       scale_exp2 = u2f(((uint32_t)scale - (uint32_t)MAX_SCALE + 127u) << 23u);
       if (scale >= 0 && scale <= MAX_SCALE) { /* pin P6: the reference reads out of bounds here; value is dead */
         if (!is_nan_ray) c->st->pop_by_scale[scale]++;
+        if (!is_nan_ray && scale < MAX_SCALE && !((pushed >> scale) & 1u)) c->st->cold_pops++;
         parent = octstack[scale].node;
         t_max = octstack[scale].tmax;
       }
@@ -700,6 +706,7 @@ int svo_oracle_render_mt(const uint8_t *pool, uint64_t pool_len, const svo_oracl
       if (svo_oracle_render_beam(pool, pool_len, prm, py, py + 1, xstep, 1, rgba, depth_out, hits, &row, NULL)) continue;
       mine.pixels += row.pixels; mine.rays += row.rays; mine.nan_rays += row.nan_rays; mine.iterations += row.iterations;
       mine.alg_bytes += row.alg_bytes; mine.descends += row.descends; mine.advances += row.advances; mine.pops += row.pops;
+      mine.cold_pops += row.cold_pops;
       if (row.max_iter > mine.max_iter) mine.max_iter = row.max_iter;
     }
 #ifdef _OPENMP
@@ -708,6 +715,7 @@ int svo_oracle_render_mt(const uint8_t *pool, uint64_t pool_len, const svo_oracl
     {
       total.pixels += mine.pixels; total.rays += mine.rays; total.nan_rays += mine.nan_rays; total.iterations += mine.iterations;
       total.alg_bytes += mine.alg_bytes; total.descends += mine.descends; total.advances += mine.advances; total.pops += mine.pops;
+      total.cold_pops += mine.cold_pops;
       if (mine.max_iter > total.max_iter) total.max_iter = mine.max_iter;
     }
   }

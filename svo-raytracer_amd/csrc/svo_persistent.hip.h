@@ -182,9 +182,11 @@ struct DescWalk {
   // a new ray starts on a zeroed stack column, like the reference's zero-initialised stack[] (svotrace.comp:227): a pop to a
   // level the ray never pushed then reads {descriptor 0, t_max 0} by itself, and the loop keeps no "pushed" mask
   __device__ __forceinline__ void fresh_stack(Stack &stk, uint32_t lane) const {
-#if SVO_ASM_LOOP && SVO_STACK_CLEAR
+#if SVO_ASM_LOOP
+    // (unconditional in the assembly build: trav_loop2's POP reads its entry without a pushed-levels mask.  Round 3's
+    // closing commit lost the define that guarded these stores and shipped a kernel without them.)
 #pragma unroll
-    for (int lv = 0; lv < kStackLevels; ++lv) stk.pm[(lv << 6) | lane] = make_uint2(0u, 0u);
+    for (int lv = 0; lv < kStackLevels; ++lv) stk.pm[lane + 64u * (uint32_t)lv] = make_uint2(0u, 0u);
 #else
     (void)stk; (void)lane;
 #endif

@@ -233,3 +233,33 @@ def test_refreshed_table_equals_a_rebuilt_one_under_random_record_edits(ctx):
         assert followed >= 10, followed
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("waves", [1, 2])
+def test_many_rays_per_lane_on_stale_stack_columns(ctx, waves):
+    """A lane of a persistent wave casts ray after ray over the same LDS stack column.  trav_loop2's POP reads its level
+    without a pushed-levels mask, so what a ray finds there must never depend on the rays before it: every ray starts on
+    a zeroed column (DescWalk::fresh_stack; tests/test_kernel_isa.py checks the stores are in the shipped kernel).  Here
+    the pressure test: one / two waves per CU over a full-HD frame -- 8 000 rays per lane, hostile cameras included --
+    against the one-thread-per-pixel pipeline, whose stack is private to its one path."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(512)
+    ctx.set_derived(1)
+    cams = [CAMERAS["K1"], CAMERAS["K2"]]
+    edge = np.array(CAMERAS["K0"], dtype=np.float32).copy()
+    edge[:3] = (1.5, 1.25, 1.75)          # the camera on cell boundaries of three levels
+    cams.append(edge)
+    tilt = np.array(CAMERAS["K1"], dtype=np.float32).copy()
+    tilt[3:] = np.float32(tilt[3:]) * np.float32([1, 0, 1] * 4) + np.float32([0, -1e-20, 0] * 4)   # axis-parallel rays: |d.y| < epsilon
+    cams.append(tilt)
+    for mode in (0, 2):
+        for cam in cams:
+            ctx.set_pipeline(0)
+            ref = ctx.render(pool, 1920, 1080, cam, 3, mode)
+            ctx.set_pipeline(1)
+            ctx.set_tuning(waves, 9)
+            got = ctx.render(None, 1920, 1080, cam, 3, mode)
+            ctx.set_tuning(0, 0)
+            bad = _same(got, ref)
+            assert bad == {k: 0 for k in bad}, (mode, cam[:3], bad)

@@ -1,0 +1,66 @@
+"""Checks on the gfx950 code object inside libsvohip.so (no GPU needed: llvm-objdump disassembles it here).
+
+Why: round 3's closing commit removed a #define and with it the 12 LDS stores that zero a lane's stack column when a ray
+is set up (DescWalk::fresh_stack).  Nothing failed -- a POP to a level its ray never pushed is so rare that no golden, no
+fuzz case and none of 900 000 random hostile cameras on the CPU oracle produces one (`cold_pops` of the oracle's
+statistics) -- so the property "the kernel that ships has the stores" is checked on the instructions themselves."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.fixture(scope="module")
+def disassembly(tmp_path_factory):
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not installed")
+    d = tmp_path_factory.mktemp("isa")
+    # --offloading writes the unbundled code objects NEXT TO ITS INPUT: work on a copy (two such files were once committed)
+    so = shutil.copy(os.path.join(ROOT, "svo-raytracer_amd", "csrc", "libsvohip.so"), d)
+    subprocess.check_call([OBJDUMP, "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
+    co = [f for f in os.listdir(d) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(d)
+    txt = subprocess.check_output([OBJDUMP, "-d", os.path.join(d, co[0])], text=True)
+    kernels = {}
+    name = None
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m and m.group(1).startswith("L") and not m.group(1).startswith("_Z"):
+            continue   # a label of the inline assembly (Ltrip1, LnoD1, ...): still the same kernel
+        if m:
+            name = m.group(1)
+            kernels[name] = []
+        elif name and line.strip():
+            kernels[name].append(line.split()[0])
+    return kernels
+
+
+def _kernel(kernels, *parts):
+    hit = [k for k in kernels if all(p in k for p in parts)]
+    assert len(hit) == 1, (parts, hit)
+    return kernels[hit[0]]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_descriptor_walk_zeroes_a_new_ray_s_stack_column(disassembly, mode):
+    """trav_loop2's POP reads {descriptor, t_max} of its level unconditionally (no pushed-levels mask): every ray must
+    start on a zeroed column = the reference's zero-initialised octstack (svotrace.comp:227).  12 levels of 8 bytes per
+    lane: six ds_write2st64_b64 (or twelve ds_write_b64) next to the loop's one PUSH (ds_write2_b32)."""
+    ins = _kernel(disassembly, "persist_kernelILi%dE" % mode, "DescWalk")
+    levels = 2 * ins.count("ds_write2st64_b64") + ins.count("ds_write_b64")
+    assert levels >= 12, {k: ins.count(k) for k in set(ins) if k.startswith("ds_")}
+    assert ins.count("ds_write2_b32") >= 1   # the PUSH
+
+
+def test_persistent_kernels_use_no_scratch_beyond_the_known_spills(disassembly):
+    """a tripwire, not a target: the descriptor walk's mode-0 kernel must keep its traversal loop free of scratch traffic
+    (spills live in round code only) -- a `scratch_` / `buffer_..._offen` spill inside the loop body would show up as a
+    jump in these counts"""
+    ins = _kernel(disassembly, "persist_kernelILi0E", "DescWalk")
+    spills = sum(1 for i in ins if i.startswith("scratch_"))
+    assert spills < 120, spills
