@@ -29,7 +29,19 @@ struct Frame {
   // outputs at element offset k * frame_stride.  1 = the reference's one dispatch per frame.
   int32_t batch;
   uint32_t frame_stride;
+  // progressive && seq > 1: this launch carries `seq` consecutive frames of the cross-frame accumulation -- frameNumber,
+  // frameNumber + 1, ... blended into ONE image in frame order, as seq dispatches of the reference's loop would
+  // (Main.java:275 + svotrace.comp:712-719).  1 = one frame per dispatch.
+  int32_t seq;
 };
+
+// What changes from frame to frame of a batch whose frames carry their own camera (svo_ring_submit_cams): the five camera
+// vectors and frameNumber (Main.updateEarly moves the camera and resets frameNumber on motion, Main.java:161-236, 275).
+struct FrameVar {
+  float cam[15];
+  int32_t frame_number;
+};
+static_assert(sizeof(FrameVar) == 64, "FrameVar is one 64-byte scalar load");
 
 // device-side counters of a counted frame
 struct DeviceCounters {

@@ -60,10 +60,19 @@ struct PersistArgs {
   uint32_t desc_count;
 };
 
-// n / d by multiply-high with m = ceil(2^32 / d) (made on the host, udiv_magic): exact while n * (m * d - 2^32) < 2^32,
-// i.e. for every n < 2^32 / d -- here n < 2^16 (tile counts) and d < 2^12
-__device__ __forceinline__ uint32_t udiv_by(uint32_t n, uint32_t d, uint32_t m) { return d <= 1u ? n : __umulhi(n, m); }
-inline uint32_t udiv_magic(uint32_t d) { return d <= 1u ? 0u : 0xffffffffu / d + 1u; }
+// n / d by multiply-high with m = ceil(2^32 / d) = (2^32 + e) / d, 0 <= e < d (made on the host, udiv_magic): with
+// n = q d + r the product is q 2^32 + q e + r (2^32 + e) / d, so the high word is q exactly while e (n + d) < 2^32.
+// The host checks that against the largest n the launch can form (tile slots of a band x frames x samples: a 4K batch of
+// 17 frames, or 1080p with 16 samples x 2 frames, is already past it) and passes m = 0 otherwise = a real division.
+__device__ __forceinline__ uint32_t udiv_by(uint32_t n, uint32_t d, uint32_t m) {
+  return d <= 1u ? n : (m == 0u ? n / d : __umulhi(n, m));
+}
+inline uint32_t udiv_magic(uint32_t d, uint64_t n_max) {
+  if (d <= 1u) return 0u;
+  const uint32_t m = 0xffffffffu / d + 1u;
+  const uint64_t e = (uint64_t)m * d - (1ull << 32);
+  return e * (n_max + d) < (1ull << 32) ? m : 0u;
+}
 
 __device__ __forceinline__ uint32_t xcc_id() {
   uint32_t x;
@@ -182,9 +191,10 @@ struct DescWalk {
   // a new ray starts on a zeroed stack column, like the reference's zero-initialised stack[] (svotrace.comp:227): a pop to a
   // level the ray never pushed then reads {descriptor 0, t_max 0} by itself, and the loop keeps no "pushed" mask
   __device__ __forceinline__ void fresh_stack(Stack &stk, uint32_t lane) const {
-#if SVO_ASM_LOOP
-    // (unconditional in the assembly build: trav_loop2's POP reads its entry without a pushed-levels mask.  Round 3's
-    // closing commit lost the define that guarded these stores and shipped a kernel without them.)
+#if SVO_ASM_LOOP && !defined(SVO_TIMING_ONLY_NO_STACK_CLEAR)
+    // (always in the assembly build: trav_loop2's POP reads its entry without a pushed-levels mask.  Round 3's closing
+    // commit lost the define that guarded these stores and shipped a kernel without them; the switch above exists to
+    // price them in an A/B and builds a WRONG kernel; tests/test_kernel_isa.py checks the shipped one.)
 #pragma unroll
     for (int lv = 0; lv < kStackLevels; ++lv) stk.pm[lane + 64u * (uint32_t)lv] = make_uint2(0u, 0u);
 #else
@@ -656,9 +666,12 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.desc = desc; a.aux = aux; a.desc_count = desc_count;
   {
     const int last_rows = a.rows_per_band > 0 ? f.tiles_y % a.rows_per_band : 0;   // the one band that is not full (if any)
-    a.mg_rows[0] = udiv_magic((uint32_t)a.rows_per_band); a.mg_rows[1] = udiv_magic((uint32_t)last_rows);
-    a.mg_tpf[0] = udiv_magic((uint32_t)(a.rows_per_band * f.tiles_x * fold));
-    a.mg_tpf[1] = udiv_magic((uint32_t)(last_rows * f.tiles_x * fold));
+    const uint32_t tpf[2] = {(uint32_t)(a.rows_per_band * f.tiles_x * fold), (uint32_t)(last_rows * f.tiles_x * fold)};
+    const uint64_t nb = (uint64_t)(f.batch > 1 ? f.batch : 1);
+    a.mg_rows[0] = udiv_magic((uint32_t)a.rows_per_band, (uint64_t)a.rows_per_band * (uint64_t)f.tiles_x);
+    a.mg_rows[1] = udiv_magic((uint32_t)last_rows, (uint64_t)last_rows * (uint64_t)f.tiles_x);
+    a.mg_tpf[0] = udiv_magic(tpf[0], nb * tpf[0]);   // n = slot >> 6 < frames x tile slots per frame
+    a.mg_tpf[1] = udiv_magic(tpf[1], nb * tpf[1]);
   }
   const long long work = (long long)f.ntiles * (f.batch > 1 ? f.batch : 1) * fold;
   const int blocks = work < (long long)b.blocks ? (int)work : b.blocks;

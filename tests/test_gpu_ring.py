@@ -227,3 +227,24 @@ def test_ring_streams_with_reserved_cus_and_device_memory_calls(ctx):
         ctx.dev_free(p)                               # already freed
     with pytest.raises(SvoError):
         ctx.ipc_close(12345)
+
+
+@pytest.mark.parametrize("w,h,spp,per", [(1920, 1080, 8, 5), (1920, 1080, 16, 2), (3840, 2160, 1, 17)])
+def test_large_batches_where_the_refill_reciprocal_is_inexact(ctx, w, h, spp, per):
+    """The refill turns a slot number into (frame of the batch, tile) with a multiply-high by ceil(2^32 / d); that is
+    exact only while e (n + d) < 2^32 (svo_persistent.hip.h::udiv_magic).  Full-HD with 8 samples x 5 frames, 16 samples
+    x 2 frames and a 4K batch of 17 frames are past it (wrong frame index for the last tiles: dropped or misplaced
+    tiles); the launch then divides for real.  Every frame of the batch = the frame dispatched alone."""
+    ctx.set_pipeline(1)
+    ctx.set_tuning(10, 9)
+    ctx.resize(w, h)
+    picks = sorted({0, per // 2, per - 1})
+    want = {k: _alone(ctx, w, h, 2 + k, 0, spp=spp) for k in picks}
+    ctx.set_params(2, 0, 0, 0, 2, 0, spp)
+    ctx.ring_create(1, per, want_hits=False)
+    s = ctx.ring_submit(2, per)
+    ctx.ring_wait(s)
+    for k in picks:
+        _eq(ctx.ring_read(s, k), want[k], hits=False)
+    ctx.ring_destroy()
+    ctx.set_tuning(0, 0)

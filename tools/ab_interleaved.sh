@@ -3,7 +3,7 @@
 # one bench run each (400 steps), then mean / min / max per variant -- for effects of a per cent, which the three-in-a-row
 # runs of r04_ab.sh cannot separate from the drift of a box
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_ab2.txt; : > $O
+O=gpurun_out/ab_interleaved.txt; : > $O
 for r in $(seq 1 ${ROUNDS:-8}); do
   for v in "" "$@"; do
     lib=$GRAFT_REPO_ROOT/svo-raytracer_amd/csrc/libsvohip${v:+_$v}.so
