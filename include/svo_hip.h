@@ -158,6 +158,18 @@ int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_sixteenth
  * frameNumber 100 on.  Default off = the live shader.  The caller keeps rendering into the same colour image and
  * resets frameNumber when the camera moves, as Main.java does (:16, :275). */
 int svo_set_progressive(svo_ctx *ctx, int enabled);
+/* BASELINE config 5 in the reference's terms ("64 spp accumulated GI" = the accumulation above over 64 frames): with
+ * svo_set_progressive(1), every dispatch renders nframes consecutive frames of the accumulation -- frameNumber,
+ * frameNumber + 1, ... frameNumber + nframes - 1 -- into the ONE colour image, exactly what nframes dispatches with
+ * frameNumber advancing leave there (Main.java:275 + svotrace.comp:712-719; depth and hit image: the last frame's).
+ * fresh != 0: the sequence starts on a zeroed image (the application's first frames: frameNumber 2 on the image
+ * glTexStorage2D left); 0: on the image as the previous dispatch left it.  On the persistent pipeline the whole sequence
+ * is ONE launch (every frame's colour kept in a slot of its own, 12 bytes per pixel and frame) followed by a pass that
+ * applies the reference's recurrence in frame order, quantising to rgba8 between frames as imageStore / imageLoad do: the
+ * same bytes as one dispatch per frame, without their tails.  Sequences that do not fit 4 GB of slots, more than one
+ * sample per pixel, and the other pipelines fall back to one launch per frame.  nframes = 1 (default): one frame per
+ * dispatch.  A sequence is one frame of a batch: svo_set_batch must be 1. */
+int svo_set_sequence(svo_ctx *ctx, int nframes, int fresh);
 /* Throughput mode: every dispatch renders `nframes` consecutive frames of the current camera -- frameNumber,
  * frameNumber + 1, ... exactly what nframes turns of Main.updateEarly with a static camera render (Main.java:275 only
  * increments frameNumber) -- frame k into the bound (caller-owned) outputs at element offset k * frame_stride (the same
@@ -222,12 +234,24 @@ int svo_ring_create(svo_ctx *ctx, int slots, int frames_per_slot, int want_hits)
  * gather) queued next to four such launches only start when a launch drains.  per_xcd > 0 makes the NEXT
  * svo_ring_create build its streams with a CU mask that leaves that many CUs of each of the 8 XCDs free
  * (hipExtStreamCreateWithCUMask), so that a collective on another stream always finds room; 0 (default) = all CUs. */
+/* NOTE: HIP offers CU-masked streams only as default (blocking) streams: unlike the ring's unreserved streams
+ * (hipStreamNonBlocking) they synchronise implicitly with the legacy null stream.  While a ring with reserved CUs has
+ * frames in flight, keep work off the null stream (hipMemcpy / hipMemset without a stream, a framework's default
+ * stream): each such call serialises against every slot.  The library's own null-stream calls are all in functions that
+ * wait for the frames anyway (svo_ring_read_*, svo_pool_update, svo_resize). */
 int svo_set_reserved_cus(svo_ctx *ctx, int per_xcd);
 int svo_ring_destroy(svo_ctx *ctx);
 /* enqueue frames frame_number .. frame_number + nframes - 1 (what nframes turns of Main.updateEarly with a static
  * camera render, Main.java:275) with the context's current camera / params / stripes / tuning into the next slot
  * (round robin; a slot's re-use is ordered behind its previous frames by its stream); returns at once. */
 int svo_ring_submit(svo_ctx *ctx, int frame_number, int nframes, int *slot);
+/* the same for a camera that moves: frame k of the submission carries its own camera -- cams[15 k .. 15 k + 14] = pos, l1,
+ * l2, r1, r2 as Camera.getUniform yields them (Camera.java:142-151) -- and its own frameNumber (Main.updateEarly moves the
+ * camera and resets frameNumber to 0 on any motion, pre-incremented to 1 before the dispatch: Main.java:161-236, 275).
+ * One persistent launch carries all nframes frames; every frame's bytes are those of svo_set_camera + svo_set_params +
+ * svo_dispatch of its own.  The context's camera and frameNumber are left as they were.  The arrays are copied before
+ * the call returns.  With nframes > 1 the beam pre-pass (one camera's) is refused. */
+int svo_ring_submit_cams(svo_ctx *ctx, int nframes, const float *cams, const int *frame_numbers, int *slot);
 /* host waits until the slot's last submission is complete */
 int svo_ring_wait(svo_ctx *ctx, int slot);
 /* non-blocking: *done = 1 when complete; the first frameNumber and the number of frames it holds; GPU milliseconds
@@ -252,7 +276,12 @@ int svo_ring_device_ptrs(svo_ctx *ctx, int slot, void **color, void **depth, voi
  * number of the submission (1, 2, ... over the ring's lifetime) into the 32-bit word *flag (owner's memory as well,
  * NULL = none): the owner knows a rank's frames have landed when the word has reached the submission it waits for.
  * Between GPUs such copies run on the SDMA engines: they need no CU slot next to the persistent waves, which an RCCL
- * send / receive does.  dst == NULL switches forwarding off. */
+ * send / receive does.  dst == NULL switches forwarding off.
+ * LOCKSTEP: the word carries the sender's submission count, so owner and senders must submit the same sequence of
+ * dispatches from ring creation on, and the owner must have read (or given up) a slot's previous frames before any rank
+ * submits into that slot again -- there is no back-pressure from the owner to the senders (a rank that ran a whole ring
+ * ahead would overwrite frames not yet read, and the word would still compare >=).  bench.py and svo_group_* (one host
+ * thread submits for every member) satisfy that by construction. */
 int svo_ring_forward_slot(svo_ctx *ctx, int slot, const void *src, void *dst, uint64_t nbytes, void *flag);
 /* device memory that can be shared with the other ranks of the node: plain allocations (zeroed), their 64-byte IPC
  * handles, and a peer's allocation opened from its handle (hipIpcGetMemHandle / hipIpcOpenMemHandle) */

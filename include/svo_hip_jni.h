@@ -93,6 +93,11 @@ jint Java_src_engine_HipRenderer_nRingCreate(void *env, void *cls, jlong ctx, ji
 jint Java_src_engine_HipRenderer_nRingDestroy(void *env, void *cls, jlong ctx);
 /* returns the slot (>= 0) the frames went to, or a negative status */
 jint Java_src_engine_HipRenderer_nRingSubmit(void *env, void *cls, jlong ctx, jint frame_number, jint nframes);
+/* a submission whose frames carry their own camera (15 floats each at cams_addr) and frameNumber (ints at
+ * frame_numbers_addr): svo_ring_submit_cams; returns the slot or a negative status */
+jint Java_src_engine_HipRenderer_nRingSubmitCams(void *env, void *cls, jlong ctx, jint nframes, jlong cams_addr, jlong frame_numbers_addr);
+/* svo_set_sequence: nframes frames of the cross-frame accumulation per dispatch (BASELINE config 5 = 64) */
+jint Java_src_engine_HipRenderer_nSetSequence(void *env, void *cls, jlong ctx, jint nframes, jint fresh);
 jint Java_src_engine_HipRenderer_nRingWait(void *env, void *cls, jlong ctx, jint slot);
 /* 1 = complete, 0 = still running, negative = status; *ms_addr (4 bytes, may be 0) = GPU milliseconds of the slot */
 jint Java_src_engine_HipRenderer_nRingDone(void *env, void *cls, jlong ctx, jint slot, jlong ms_addr);

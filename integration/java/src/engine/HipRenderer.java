@@ -224,6 +224,38 @@ public class HipRenderer {
     return slot;
   }
 
+  /**
+   * The same for a camera that moves: frame k carries cams[k] (float[15]: pos, l1, l2, r1, r2 = Camera.getUniform(),
+   * Camera.java:142-151) and frameNumbers[k] (Main.updateEarly resets frameNumber on motion: Main.java:161-236, 275).
+   * One launch carries all the frames.  Returns the slot, or a negative status.  Does not wait.
+   */
+  public int submitFrames(float[][] cams, int[] frameNumbers) {
+    int n = frameNumbers.length;
+    check(nSetParams(ctx, frameNumbers[0], renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+    ByteBuffer c = MemoryUtil.memAlloc(60 * n), f = MemoryUtil.memAlloc(4 * n);
+    for (int k = 0; k < n; k++) {
+      for (int i = 0; i < 15; i++)
+        c.putFloat(60 * k + 4 * i, cams[k][i]);
+      f.putInt(4 * k, frameNumbers[k]);
+    }
+    int slot = nRingSubmitCams(ctx, n, MemoryUtil.memAddress(c), MemoryUtil.memAddress(f));
+    MemoryUtil.memFree(c);
+    MemoryUtil.memFree(f);
+    if (slot < 0)
+      printGLErrors();
+    else
+      frameNumber = frameNumbers[n - 1];
+    return slot;
+  }
+
+  /**
+   * BASELINE config 5 in the reference's terms: with setProgressive(true), every dispatch / submitFrames(f, 1) renders
+   * nframes consecutive frames of the accumulation of svotrace.comp:712-719 into the one image (svo_set_sequence).
+   */
+  public void setSequence(int nframes, boolean fresh) {
+    check(nSetSequence(ctx, nframes, fresh ? 1 : 0));
+  }
+
   /** Block until the frames of a slot are complete. */
   public void awaitFrames(int slot) {
     check(nRingWait(ctx, slot));
@@ -315,6 +347,8 @@ public class HipRenderer {
   private static native int nRingCreate(long ctx, int slots, int framesPerSlot, int wantHits);
   private static native int nRingDestroy(long ctx);
   private static native int nRingSubmit(long ctx, int frameNumber, int nframes);
+  private static native int nRingSubmitCams(long ctx, int nframes, long camsAddr, long frameNumbersAddr);
+  private static native int nSetSequence(long ctx, int nframes, int fresh);
   private static native int nRingWait(long ctx, int slot);
   private static native int nRingDone(long ctx, int slot, long msAddr);
   private static native int nRingReadColor(long ctx, int slot, int k, long addr);

@@ -18,3 +18,23 @@ CAMERAS = {
     "K1": rot_cam((1.5, 1.42, 1.5), -0.5, 0.3),     # inside the cube, pitched toward the terrain
     "K2": rot_cam((1.2, 1.40, 1.8), -0.08, 0.7),    # grazing view
 }
+
+
+def orbit_path(n, start="K1", yaw_step=0.004, pitch_step=0.0, forward=0.0004, side=0.0002):
+    """A deterministic moving-camera sequence through the host mirror of the reference's Camera (host/svo_host.hpp <->
+    Camera.java:46-50, 76-140): from camera `start`'s position, n frames of rotate(pitch_step, yaw_step, 0) + strafe(forward,
+    side) -- what Main.updateEarly does on key / mouse input (Main.java:161-236).  Returns (cams float32 [n][15],
+    frame_numbers int32 [n]): every frame moved the camera, so Main resets frameNumber to 0 and pre-increments it: 1
+    (Main.java:225-233, 275)."""
+    from . import hostlib
+    cam = hostlib.Camera()
+    p = CAMERAS[start][:3]
+    cam.setPos(float(p[0]), float(p[1]), float(p[2]))
+    cam.setSpeed(1.0)
+    cam.rotate(-0.5, 0.3, 0.0)     # K1's attitude, through the reference's own rotate()
+    out = np.zeros((n, 15), dtype=np.float32)
+    for i in range(n):
+        cam.rotate(pitch_step, yaw_step, 0.0)
+        cam.strafe(forward, side)
+        out[i] = cam.getUniform()
+    return out, np.ones(n, dtype=np.int32)

@@ -26,20 +26,23 @@ __device__ __forceinline__ float beam_start(const Frame &f, int px, int py) {
 // dormant cross-frame accumulation (:712-719) is switched on -- the running mean with the image the previous frame left
 // in the colour buffer: (frameNumber * last + colour) / (frameNumber + 1), frozen from MAX_FRAME_ITER = 100 on.
 // imageLoad of rgba8 = byte * (1/255); true division (both pinned by tests/golden/accum_golden.npz).
-__device__ __forceinline__ uint32_t final_rgba8(const Frame &f, int px, int py, V3 col, const uint32_t *dst) {
+// `last`: the texel the previous frame left (only looked at when the accumulation is on); frame_number: this frame's
+__device__ __forceinline__ uint32_t final_rgba8_v(const Frame &f, int frame_number, int px, int py, V3 col, uint32_t last) {
   if (px < 10 && py < 10) col = f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
-  if (f.progressive && f.frame_number > 1) {
-    const uint32_t last = *dst;
+  if (f.progressive && frame_number > 1) {
     const V3 lc = mk((float)(last & 0xffu) * (1.0f / 255.0f), (float)((last >> 8) & 0xffu) * (1.0f / 255.0f),
                      (float)((last >> 16) & 0xffu) * (1.0f / 255.0f));
-    if (f.frame_number < 100) {
-      const float fn = (float)f.frame_number, fd = (float)(f.frame_number + 1);
+    if (frame_number < 100) {
+      const float fn = (float)frame_number, fd = (float)(frame_number + 1);
       col = mk((fn * lc.x + col.x) / fd, (fn * lc.y + col.y) / fd, (fn * lc.z + col.z) / fd);
     } else {
       col = lc;
     }
   }
   return unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
+}
+__device__ __forceinline__ uint32_t final_rgba8(const Frame &f, int px, int py, V3 col, const uint32_t *dst) {
+  return final_rgba8_v(f, f.frame_number, px, py, col, (f.progressive && f.frame_number > 1) ? *dst : 0u);
 }
 
 __device__ __forceinline__ V3 sky_colour(V3 d) {
@@ -162,13 +165,17 @@ __device__ __forceinline__ void trace_sample(const Pool &pool, WaveStack &stk, u
   out_depth = depth;
 }
 
-__device__ __forceinline__ V3 primary_direction(const Frame &f, int px, int py) {
-  const float u = ((float)px + 0.5f) / (float)f.width;
-  const float v = ((float)py + 0.5f) / (float)f.height;
-  const float *c = f.cam;
+// c: the 15 camera floats (pos, l1, l2, r1, r2), any address space
+template <class CamPtr>
+__device__ __forceinline__ V3 primary_direction_cam(CamPtr c, int width, int height, int px, int py) {
+  const float u = ((float)px + 0.5f) / (float)width;
+  const float v = ((float)py + 0.5f) / (float)height;
   const V3 a = mk(mix_g(c[3], c[6], v), mix_g(c[4], c[7], v), mix_g(c[5], c[8], v));
   const V3 b = mk(mix_g(c[9], c[12], v), mix_g(c[10], c[13], v), mix_g(c[11], c[14], v));
   return normalize3(mk(mix_g(a.x, b.x, u), mix_g(a.y, b.y, u), mix_g(a.z, b.z, u)));
+}
+__device__ __forceinline__ V3 primary_direction(const Frame &f, int px, int py) {
+  return primary_direction_cam(f.cam, f.width, f.height, px, py);
 }
 
 // blockIdx -> tile so that the 8 XCDs (blocks are dealt to them round-robin) each take a

@@ -37,6 +37,9 @@ struct svo_ctx {
   bool rows_set = false;
   int row_step = 1, out_y0 = 0, n_tile_rows = -1;  // stripe mode (svo_set_stripes); n_tile_rows < 0 = band mode
   int frame_number = 2, render_mode = 2, buffer_end = 0, use_beam = 0, bounces = 2, spp = 1, progressive = 0;
+  int seq = 1, seq_fresh = 0;    // progressive: frames of the accumulation per dispatch, on a zeroed image or not (svo_set_sequence)
+  const FrameVar *batch_cams = nullptr;     // host copy of the cameras / frame numbers of the batch being submitted
+  const FrameVar *batch_cams_dev = nullptr; // (svo_ring_submit_cams), and where the slot keeps them on the device
   int batch = 1;                 // frames per dispatch (svo_set_batch)
   uint64_t frame_stride = 0;     // elements between consecutive frames of a batch in each output
   uint32_t mirror_mask = 0;
@@ -72,10 +75,14 @@ struct svo_ctx {
   struct RingSlot {
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e2 = nullptr;      // behind the forward copy of the last submission (svo_ring_forward_slot), made on demand
     uint32_t *color = nullptr; float *depth = nullptr; uint4 *hits = nullptr;      // library-owned
     void *xcolor = nullptr, *xdepth = nullptr, *xhits = nullptr; uint64_t xstride = 0;   // caller-owned (svo_ring_bind_slot)
     int first_frame = 0, nframes = 0;
     bool used = false;
+    FrameVar *d_fvar = nullptr;   // per-frame cameras of the slot's last submission (svo_ring_submit_cams) ...
+    FrameVar *h_fvar = nullptr;   // ... their pinned staging copy, and the event behind the copy that last read it
+    hipEvent_t fvar_copied = nullptr;
     // svo_ring_forward_slot: after every submission, src -> dst (a peer's memory) and the submission's number -> *fwd_flag
     const void *fwd_src = nullptr; void *fwd_dst = nullptr; uint64_t fwd_bytes = 0; void *fwd_flag = nullptr;
     uint32_t *seq_word = nullptr;
@@ -136,7 +143,11 @@ static void ring_free(svo_ctx *c) {
     if (s.hits) (void)hipFree(s.hits);
     if (s.e0) (void)hipEventDestroy(s.e0);
     if (s.e1) (void)hipEventDestroy(s.e1);
+    if (s.e2) (void)hipEventDestroy(s.e2);
     if (s.seq_word) (void)hipFree(s.seq_word);
+    if (s.d_fvar) (void)hipFree(s.d_fvar);
+    if (s.h_fvar) (void)hipHostFree(s.h_fvar);
+    if (s.fvar_copied) (void)hipEventDestroy(s.fvar_copied);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   c->ring.clear();
@@ -514,6 +525,13 @@ int svo_set_progressive(svo_ctx *c, int enabled) {
   return SVO_OK;
 }
 
+int svo_set_sequence(svo_ctx *c, int nframes, int fresh) {
+  if (!c || nframes < 1 || nframes > 4096) return fail(c, SVO_E_INVALID, "svo_set_sequence: 1..4096 frames");
+  c->seq = nframes;
+  c->seq_fresh = fresh ? 1 : 0;
+  return SVO_OK;
+}
+
 int svo_set_hit_records(svo_ctx *c, int enabled) {
   if (!c) return SVO_E_INVALID;
   c->write_hits = enabled ? 1 : 0;
@@ -550,7 +568,7 @@ static int make_frame(svo_ctx *c, Frame &f) {
   f.write_hits = (c->write_hits && c->d_hits) ? 1 : 0;
   f.use_beam = 0; f.beam_w = 0; f.beam = nullptr;
   f.progressive = c->progressive;
-  f.batch = 1; f.frame_stride = 0;
+  f.batch = 1; f.frame_stride = 0; f.seq = 1;
   if (!c->external_outputs && c->n_tile_rows > 0) {
     // packed stripes land at output rows out_y0 + 8 j + ly: they must stay inside the library's W x H images
     // (caller-owned gather buffers are the caller's to size, see svo_bind_outputs)
@@ -654,7 +672,32 @@ static int launch_frame(svo_ctx *c, bool count) {
   if (nb > 1 && f.progressive)
     return fail(c, SVO_E_INVALID, "svo_set_batch: cross-frame accumulation blends into ONE image frame after frame; "
                                   "a batch writes every frame to its own");
-  if (nb > 1 && c->pipeline == 1) {
+  if (nb > 1 && c->batch_cams && c->use_beam)
+    return fail(c, SVO_E_INVALID, "svo_ring_submit_cams: the beam pre-pass belongs to one camera; submit such frames one by one");
+  if (f.progressive && (c->seq > 1 || c->seq_fresh) && !count) {
+    // a progressive sequence: c->seq frames of the accumulation, frameNumber, frameNumber + 1, ..., into the one image
+    if (c->seq_fresh) {   // ... starting on a zeroed image (the application's first frames; the image after glTexStorage2D)
+      int last_row = f.out_y0;
+      for (int j = f.tiles_y - 1; j >= 0; j--) {
+        const long long gy = (long long)f.y0 + (long long)j * 8 * f.row_step;
+        if (gy < (long long)std::min(f.height, f.y1)) { last_row = f.out_y0 + j * 8 + (int)std::min<long long>(8, std::min(f.height, f.y1) - gy); break; }
+      }
+      if (last_row > f.out_y0)
+        HIPCHK(c, hipMemsetAsync(c->d_color + (size_t)f.out_y0 * (size_t)f.width, 0, (size_t)(last_row - f.out_y0) * (size_t)f.width * 4, c->stream));
+    }
+    Frame probe = f;
+    if (c->pipeline == 1 && f.spp <= 1 && persist_can_fold(probe, c->seq)) {
+      // the persistent pipeline carries the whole sequence in one launch and blends it in frame order afterwards
+      f.seq = c->seq;
+      rc = launch_frame_kernels(c, f, count, c->d_color, c->d_depth, c->d_hits);
+    } else {
+      for (int k = 0; k < c->seq && rc == SVO_OK; k++) {
+        Frame g = f;
+        g.frame_number = f.frame_number + k;
+        rc = launch_frame_kernels(c, g, count, c->d_color, c->d_depth, c->d_hits);
+      }
+    }
+  } else if (nb > 1 && c->pipeline == 1) {
     // the persistent pipeline takes the whole batch as one launch: its waves go from frame to frame without a tail
     f.batch = nb;
     f.frame_stride = (uint32_t)c->frame_stride;
@@ -663,6 +706,7 @@ static int launch_frame(svo_ctx *c, bool count) {
     for (int k = 0; k < nb && rc == SVO_OK; k++) {
       Frame g = f;
       g.frame_number = f.frame_number + k;
+      if (c->batch_cams) { memcpy(g.cam, c->batch_cams[k].cam, sizeof g.cam); g.frame_number = c->batch_cams[k].frame_number; }
       const size_t o = (size_t)k * (size_t)c->frame_stride;
       rc = launch_frame_kernels(c, g, count, c->d_color + o, c->d_depth + o, c->d_hits ? c->d_hits + o : nullptr);
     }
@@ -683,7 +727,7 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
     if (mode != 0 && (rc = ensure_derived(c)) != SVO_OK) return rc;
     const bool walk_table = mode != 0 && c->dt.ok;   // not derivable (deeper than 13 levels, cyclic): the records are walked
     rc = persist_launch(c->pb, c->d_pool, f, color, depth, hits, out_elems(c, f), c->stream, walk_table ? c->dt.desc : nullptr,
-                        walk_table ? c->dt.aux : nullptr, walk_table ? c->dt.count : 0u);
+                        walk_table ? c->dt.aux : nullptr, walk_table ? c->dt.count : 0u, c->batch_cams ? c->batch_cams_dev : nullptr);
     if (rc) return fail(c, SVO_E_HIP, std::string("persistent pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
@@ -850,17 +894,20 @@ int svo_ring_bind_slot(svo_ctx *c, int slot, void *color, void *depth, void *hit
   return SVO_OK;
 }
 
-int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
+// `cams`: null = nframes consecutive frames of the context's camera starting at frame_number (svo_ring_submit); else nframes
+// entries, every frame with its own camera and frameNumber (svo_ring_submit_cams)
+static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar *cams, int *slot, const char *who) {
   if (!c) return SVO_E_INVALID;
-  if (c->ring.empty()) return fail(c, SVO_E_INVALID, "svo_ring_submit: svo_ring_create first");
-  if (nframes < 1 || nframes > c->ring_frames) return fail(c, SVO_E_INVALID, "svo_ring_submit: 1..frames_per_slot frames");
+  if (c->ring.empty()) return fail(c, SVO_E_INVALID, std::string(who) + ": svo_ring_create first");
+  if (nframes < 1 || nframes > c->ring_frames) return fail(c, SVO_E_INVALID, std::string(who) + ": 1..frames_per_slot frames");
   HIPCHK(c, hipSetDevice(c->device));
   const int si = (int)(c->ring_next % (unsigned)c->ring.size());
   svo_ctx::RingSlot &s = c->ring[(size_t)si];
   // the dispatch state of the context, with this slot's stream, images and frame range swapped in
   struct Saved {
-    hipStream_t stream; uint32_t *col; float *dep; uint4 *hit; bool ext; int batch; uint64_t stride; int frame;
-  } const sv = {c->stream, c->d_color, c->d_depth, c->d_hits, c->external_outputs, c->batch, c->frame_stride, c->frame_number};
+    hipStream_t stream; uint32_t *col; float *dep; uint4 *hit; bool ext; int batch; uint64_t stride; int frame; float cam[15];
+  } sv = {c->stream, c->d_color, c->d_depth, c->d_hits, c->external_outputs, c->batch, c->frame_stride, c->frame_number, {}};
+  memcpy(sv.cam, c->cam, sizeof sv.cam);
   c->stream = s.stream;
   c->external_outputs = true;
   if (s.xcolor) { c->d_color = (uint32_t *)s.xcolor; c->d_depth = (float *)s.xdepth; c->d_hits = (uint4 *)s.xhits; c->frame_stride = s.xstride; }
@@ -868,7 +915,29 @@ int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
   c->batch = nframes;
   c->frame_number = frame_number;
   int rc = SVO_OK;
-  hipError_t e = hipEventRecord(s.e0, s.stream);
+  hipError_t e = hipSuccess;
+  if (cams && nframes == 1) {           // one frame: simply this frame's camera (beam pre-pass and all)
+    memcpy(c->cam, cams[0].cam, sizeof c->cam);
+    c->frame_number = cams[0].frame_number;
+  } else if (cams) {
+    // the batch's cameras travel to the slot's table on its stream, in front of the launch that reads them, out of a
+    // pinned staging copy that is rewritten only once the copy that last read it has run
+    if (!s.d_fvar) {
+      e = hipMalloc((void **)&s.d_fvar, (size_t)c->ring_frames * sizeof(FrameVar));
+      if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_fvar, (size_t)c->ring_frames * sizeof(FrameVar), hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&s.fvar_copied, hipEventDisableTiming);
+    } else {
+      e = hipEventSynchronize(s.fvar_copied);
+    }
+    if (e == hipSuccess) {
+      memcpy(s.h_fvar, cams, (size_t)nframes * sizeof(FrameVar));
+      e = hipMemcpyAsync(s.d_fvar, s.h_fvar, (size_t)nframes * sizeof(FrameVar), hipMemcpyHostToDevice, s.stream);
+    }
+    if (e == hipSuccess) e = hipEventRecord(s.fvar_copied, s.stream);
+    c->batch_cams = cams; c->batch_cams_dev = s.d_fvar;
+    c->frame_number = cams[0].frame_number;
+  }
+  if (e == hipSuccess) e = hipEventRecord(s.e0, s.stream);
   if (e == hipSuccess) rc = launch_frame(c, false);
   if (e == hipSuccess && rc == SVO_OK) e = hipEventRecord(s.e1, s.stream);
   if (e == hipSuccess && rc == SVO_OK && s.fwd_dst) {
@@ -879,15 +948,33 @@ int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
       e = hipMemsetD32Async((hipDeviceptr_t)s.seq_word, (int)(c->ring_next + 1u), 1, s.stream);
       if (e == hipSuccess) e = hipMemcpyAsync(s.fwd_flag, s.seq_word, 4, hipMemcpyDeviceToDevice, s.stream);
     }
+    if (e == hipSuccess && s.e2) e = hipEventRecord(s.e2, s.stream);
   }
   c->stream = sv.stream; c->d_color = sv.col; c->d_depth = sv.dep; c->d_hits = sv.hit; c->external_outputs = sv.ext;
   c->batch = sv.batch; c->frame_stride = sv.stride; c->frame_number = sv.frame;
-  if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string("svo_ring_submit: ") + hipGetErrorString(e));
+  memcpy(c->cam, sv.cam, sizeof c->cam);
+  c->batch_cams = nullptr; c->batch_cams_dev = nullptr;
+  if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string(who) + ": " + hipGetErrorString(e));
   if (rc) return rc;
-  s.first_frame = frame_number; s.nframes = nframes; s.used = true;
+  s.first_frame = cams ? cams[0].frame_number : frame_number; s.nframes = nframes; s.used = true;
   c->ring_next++;
   if (slot) *slot = si;
   return SVO_OK;
+}
+
+int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
+  return ring_submit(c, frame_number, nframes, nullptr, slot, "svo_ring_submit");
+}
+
+int svo_ring_submit_cams(svo_ctx *c, int nframes, const float *cams, const int *frame_numbers, int *slot) {
+  if (!c || !cams || !frame_numbers) return fail(c, SVO_E_INVALID, "svo_ring_submit_cams: null array");
+  if (nframes < 1 || nframes > 64) return fail(c, SVO_E_INVALID, "svo_ring_submit_cams: 1..frames_per_slot frames");
+  FrameVar v[64];
+  for (int k = 0; k < nframes; k++) {
+    memcpy(v[k].cam, cams + 15 * (size_t)k, sizeof v[k].cam);
+    v[k].frame_number = frame_numbers[k];
+  }
+  return ring_submit(c, frame_numbers[0], nframes, v, slot, "svo_ring_submit_cams");
 }
 
 int svo_ring_wait(svo_ctx *c, int slot) {

@@ -122,6 +122,14 @@ jint Java_src_engine_HipRenderer_nRingSubmit(void *, void *, jlong ctx, jint fra
   const int rc = svo_ring_submit(CTX(ctx), frame_number, nframes, &slot);
   return rc == SVO_OK ? slot : rc;
 }
+jint Java_src_engine_HipRenderer_nRingSubmitCams(void *, void *, jlong ctx, jint nframes, jlong cams_addr, jlong frame_numbers_addr) {
+  int slot = -1;
+  const int rc = svo_ring_submit_cams(CTX(ctx), nframes, (const float *)(intptr_t)cams_addr, (const int *)(intptr_t)frame_numbers_addr, &slot);
+  return rc == SVO_OK ? slot : rc;
+}
+jint Java_src_engine_HipRenderer_nSetSequence(void *, void *, jlong ctx, jint nframes, jint fresh) {
+  return svo_set_sequence(CTX(ctx), nframes, fresh);
+}
 jint Java_src_engine_HipRenderer_nRingWait(void *, void *, jlong ctx, jint slot) { return svo_ring_wait(CTX(ctx), slot); }
 jint Java_src_engine_HipRenderer_nRingDone(void *, void *, jlong ctx, jint slot, jlong ms_addr) {
   int done = 0;

@@ -58,6 +58,8 @@ struct PersistArgs {
   const uint2 *desc;
   const uint2 *aux;
   uint32_t desc_count;
+  // per-frame cameras and frame numbers of a batch (svo_ring_submit_cams), f.batch entries; only read by the kCams kernels
+  const FrameVar *fvar;
 };
 
 // n / d by multiply-high with m = ceil(2^32 / d) = (2^32 + e) / d, 0 <= e < d (made on the host, udiv_magic): with
@@ -104,7 +106,8 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
     if (a.sample == 0) { *fx = 0.0f + col.x; *fy = 0.0f + col.y; *fz = 0.0f + col.z; }
     else { *fx = *fx + col.x; *fy = *fy + col.y; *fz = *fz + col.z; }
   }
-  if (a.sample == 0 && smp == 0u) a.depth[pix] = depth;
+  // the depth image is the first sample's; of a progressive sequence (every "sample" a frame of its own) the last frame's
+  if (a.sample == 0 && smp == (a.f.seq > 1 ? (uint32_t)(a.fold - 1) : 0u)) a.depth[pix] = depth;
 }
 
 // SVO_ASM_LOOP=1 (default): the trips run in trav_loop() / trav_loop2() (gfx950 assembly);
@@ -243,7 +246,10 @@ struct DescWalk {
 template <class Walk> struct WalkWaves { static constexpr int value = SVO_PERSIST_WAVES_PER_SIMD; };
 template <> struct WalkWaves<DescWalk> { static constexpr int value = SVO_DERIVED_WAVES_PER_SIMD; };
 
-template <int kMode, class Walk>
+// kCams: the frames of the batch carry their own camera and frameNumber (a.fvar) -- a kernel of its own, so that the
+// static-camera kernel keeps the camera in SGPRs from its kernel arguments
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <int kMode, class Walk, bool kCams = false>
 __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(const PersistArgs a) {
   __shared__ typename Walk::Stack stk;
   const uint32_t lane = threadIdx.x;
@@ -373,6 +379,7 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
     // ---------------- refill idle lanes: ballot + prefix count, one atomic per wave
     // (a wave whose band is used up tries the next band in its next round; SVO_STEAL_NOW=1 tries it in the same round:
     // 1-4 % slower -- tools/history/r03_ab_drain.sh)
+    uint32_t cam_frame = 0u; int cam_sample = 0; bool cam_fresh = false;   // kCams only
     while (bands_left > 0) {
       const unsigned long long idle = __ballot(status == ST_IDLE);
       if (idle == 0ull) break;
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
 #else
             pix = (uint32_t)frame_oy(f, tile_y, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
 #endif
-            d = primary_direction(f, px, py);
+            if (!kCams) d = primary_direction(f, px, py);
 #if SVO_BAND_COLMAJOR
             seg = a.fold > 1 ? (si << 8) | (fi << 24) : 0u;
 #else
@@ -449,12 +456,35 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             value = 0u;
             depth = 0.0f;
 #if SVO_BAND_COLMAJOR
-            if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + (int)fi + a.sample + (int)si));
+            if (kMode == 0 && !kCams) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + (int)fi + a.sample + (int)si));
+            if (kCams) { cam_frame = fi; cam_sample = a.sample + (int)si; cam_fresh = true; }
 #else
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
 #endif
             ninit = true; icone = false; io = cam_o; its = beam_start(f, px, py);
             status = ST_ACTIVE;   // taken (the set-up below gives the real status)
+          }
+        }
+        if (kCams) {
+          // the camera of every refilled lane's frame: the slots of one draw are consecutive, so nearly always all lanes
+          // are in one frame -- one 64-byte scalar load per distinct frame, the lanes of that frame take their ray from it
+          unsigned long long todo = __ballot(cam_fresh);
+          while (todo != 0ull) {
+            const uint32_t fu = (uint32_t)__builtin_amdgcn_readlane((int)cam_frame, __builtin_ctzll(todo));
+            const FrameVar *vp = a.fvar + fu;
+            u32x16 raw;   // = *vp: cam[0..14], frame_number
+            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(vp) : "memory");
+            const bool mine = cam_fresh && cam_frame == fu;
+            if (mine) {
+              float cam[15];
+#pragma unroll
+              for (int i = 0; i < 15; i++) cam[i] = __uint_as_float(raw[i]);
+              d = primary_direction_cam(cam, f.width, f.height, px, py);
+              io = mk(cam[0], cam[1], cam[2]);
+              if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)((int)raw[15] + cam_sample));
+              cam_fresh = false;
+            }
+            todo &= ~__ballot(mine);
           }
         }
         if (base + n >= band_total) {  // this band is used up: move on (work stealing)
@@ -559,7 +589,10 @@ inline void persist_free(PersistBuffers &b) {
 
 template <int kMode>
 inline void persist_launch_mode(const PersistArgs &a, int blocks, hipStream_t stream) {
-  if (a.desc) hipLaunchKernelGGL((persist_kernel<kMode, DescWalk>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  if (a.fvar) {
+    if (a.desc) hipLaunchKernelGGL((persist_kernel<kMode, DescWalk, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((persist_kernel<kMode, ByteWalk, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+  } else if (a.desc) hipLaunchKernelGGL((persist_kernel<kMode, DescWalk>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((persist_kernel<kMode, ByteWalk>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
 }
 
@@ -588,12 +621,37 @@ __global__ __launch_bounds__(64) void persist_resolve_tiles_kernel(const Frame f
   color[pix] = final_rgba8(f, x, y, mk(sum.x * inv, sum.y * inv, sum.z * inv), color + pix);
 }
 
+// A progressive sequence (f.seq frames of the cross-frame accumulation in one launch, every frame's colour in a slot of its
+// own like a sample): the reference's recurrence in frame order -- blend with the texel the previous frame left, quantise to
+// rgba8 exactly as imageStore / imageLoad do (svotrace.comp:712-719, pins in svo_fused.hip.h::final_rgba8_v), next frame.
+// What f.seq dispatches of one frame each would leave in the image, bit for bit; `color` holds the image the sequence starts on.
+__global__ __launch_bounds__(64) void persist_resolve_sequence_kernel(const Frame f, const float *facc, int fold, uint32_t *color) {
+  const uint32_t l = threadIdx.x, tx = blockIdx.x, ty = blockIdx.y;
+  const float *p = facc + (((size_t)ty * f.tiles_x + tx) * (size_t)fold) * 192 + l;
+  const int x = (int)(tx * 8u + (l & 7u)), y = frame_gy(f, (int)ty, (int)(l >> 3));
+  if (x >= f.width || y >= f.y1 || y >= f.height) return;
+  const size_t pix = (size_t)frame_oy(f, (int)ty, (int)(l >> 3)) * f.width + x;
+  uint32_t last = color[pix];
+  for (int i = 0; i < fold; i++)
+    last = final_rgba8_v(f, f.frame_number + i, x, y, mk(0.0f + p[192 * i], 0.0f + p[192 * i + 64], 0.0f + p[192 * i + 128]), last);
+  color[pix] = last;
+}
+
+// can `n` samples (or frames of a progressive sequence) per pixel be carried by one launch of `f`?
+inline bool persist_can_fold(const Frame &f, int n) {
+  const unsigned long long nb = (unsigned long long)(f.batch > 1 ? f.batch : 1);
+  const unsigned long long bytes = 192ull * (unsigned long long)n * (unsigned long long)f.ntiles * nb * sizeof(float);
+  static const unsigned long long budget = getenv("SVO_FOLD_BYTES") ? strtoull(getenv("SVO_FOLD_BYTES"), nullptr, 10) : (4ull << 30);
+  return SVO_BAND_COLMAJOR && n > 1 && f.bounces <= 255 && bytes <= budget && f.batch <= 255 && n < 65536 &&
+         (long long)f.ntiles * (long long)nb * n < (1ll << 25);
+}
+
 // `out_npix` = elements of the output images: W*H, or more when packed stripes overhang the frame (caller-owned
 // gather buffers); the colour-sum planes are indexed like the outputs.
 // `desc` / `aux` / `desc_count`: the interior-descriptor table of the pool (svo_derive.hip.h), or null = walk the records
 inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f, uint32_t *color, float *depth,
                           uint4 *hits, size_t out_npix, hipStream_t stream, const uint2 *desc = nullptr,
-                          const uint2 *aux = nullptr, uint32_t desc_count = 0) {
+                          const uint2 *aux = nullptr, uint32_t desc_count = 0, const FrameVar *fvar = nullptr) {
   // the colour-sum planes are indexed like the outputs: a batch needs room for all its frames
   const size_t npix = f.batch > 1 ? std::max(out_npix, (size_t)f.batch * (size_t)f.frame_stride) : out_npix;
   hipError_t e;
@@ -632,12 +690,13 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   // per sample.  Same bytes either way (tests/test_gpu_inflight.py).
   int fold = 1;
   unsigned long long slots = 0;
-  if (spp > 1 && f.bounces <= 255 && SVO_BAND_COLMAJOR) {
-    slots = 192ull * (unsigned long long)spp * (unsigned long long)f.ntiles * (f.batch > 1 ? f.batch : 1);
-    const unsigned long long bytes = slots * sizeof(float);
-    static const unsigned long long budget = getenv("SVO_FOLD_BYTES") ? strtoull(getenv("SVO_FOLD_BYTES"), nullptr, 10) : (4ull << 30);
-    if (bytes <= budget && f.batch <= 255 && spp < 65536 && (long long)f.ntiles * (f.batch > 1 ? f.batch : 1) * spp < (1ll << 25)) fold = spp;
+  const bool sequence = f.progressive && f.seq > 1;   // the caller has checked persist_can_fold(f, f.seq) and spp == 1
+  const int per_pixel = sequence ? f.seq : spp;
+  if (persist_can_fold(f, per_pixel)) {
+    fold = per_pixel;
+    slots = 192ull * (unsigned long long)fold * (unsigned long long)f.ntiles * (f.batch > 1 ? f.batch : 1);
   }
+  if (sequence && (fold != f.seq || spp != 1)) return (int)hipErrorInvalidValue;
   if (resolve) {
     const size_t need = fold > 1 ? (size_t)slots : 3 * npix;   // floats per buffer
     if (b.facc_floats < need) {   // grow: nothing may still be summing into the old buffers
@@ -664,6 +723,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.fold = fold;
   a.group = kFoldGroup;
   a.desc = desc; a.aux = aux; a.desc_count = desc_count;
+  a.fvar = fvar;
   {
     const int last_rows = a.rows_per_band > 0 ? f.tiles_y % a.rows_per_band : 0;   // the one band that is not full (if any)
     const uint32_t tpf[2] = {(uint32_t)(a.rows_per_band * f.tiles_x * fold), (uint32_t)(last_rows * f.tiles_x * fold)};
@@ -696,7 +756,9 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   if ((e = hipEventRecord(b.head_done[hset], stream)) != hipSuccess) return (int)e;
   b.head_used[hset] = true;
   if (resolve) {
-    if (fold > 1) {
+    if (sequence) {
+      hipLaunchKernelGGL(persist_resolve_sequence_kernel, dim3((unsigned)f.tiles_x, (unsigned)f.tiles_y), dim3(64), 0, stream, f, facc, fold, color);
+    } else if (fold > 1) {
       dim3 grid((unsigned)f.tiles_x, (unsigned)f.tiles_y, (unsigned)(f.batch > 1 ? f.batch : 1));
       hipLaunchKernelGGL(persist_resolve_tiles_kernel, grid, dim3(64), 0, stream, f, facc, fold, color);
     } else {

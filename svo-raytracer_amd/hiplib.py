@@ -21,7 +21,7 @@ EXPORTS = [
     "svo_ring_create", "svo_ring_destroy", "svo_ring_submit", "svo_ring_wait", "svo_ring_query", "svo_ring_read_color",
     "svo_ring_read_depth", "svo_ring_read_hits", "svo_ring_read_pixel", "svo_ring_bind_slot", "svo_ring_device_ptrs",
     "svo_set_reserved_cus", "svo_pool_commit", "svo_ring_forward_slot", "svo_dev_alloc", "svo_dev_free", "svo_dev_read",
-    "svo_ipc_export", "svo_ipc_open", "svo_ipc_close",
+    "svo_ipc_export", "svo_ipc_open", "svo_ipc_close", "svo_set_sequence", "svo_ring_submit_cams",
 ]
 
 
@@ -89,6 +89,8 @@ def lib(path=None):
         L.svo_ipc_open.argtypes = [vp, vp, ctypes.POINTER(vp)]
         L.svo_ipc_close.argtypes = [vp, vp]
         L.svo_ring_submit.argtypes = [vp, ci, ci, ip]
+        L.svo_ring_submit_cams.argtypes = [vp, ci, vp, vp, ip]
+        L.svo_set_sequence.argtypes = [vp, ci, ci]
         L.svo_ring_wait.argtypes = [vp, ci]
         L.svo_ring_query.argtypes = [vp, ci, ip, ip, ip, fp]
         L.svo_ring_read_color.argtypes = [vp, ci, ci, vp]
@@ -254,6 +256,10 @@ class HipContext:
     def set_progressive(self, on):
         self._chk(self._L.svo_set_progressive(self._h, 1 if on else 0))
 
+    def set_sequence(self, nframes, fresh=True):
+        """progressive: frames of the cross-frame accumulation per dispatch (svo_set_sequence)"""
+        self._chk(self._L.svo_set_sequence(self._h, int(nframes), 1 if fresh else 0))
+
     def set_hit_records(self, on):
         self._chk(self._L.svo_set_hit_records(self._h, 1 if on else 0))
 
@@ -273,6 +279,15 @@ class HipContext:
     def ring_submit(self, frame_number, nframes=1):
         slot = ctypes.c_int()
         self._chk(self._L.svo_ring_submit(self._h, int(frame_number), int(nframes), ctypes.byref(slot)))
+        return int(slot.value)
+
+    def ring_submit_cams(self, cams, frame_numbers):
+        """one submission whose frames carry their own camera (15 floats each) and frameNumber (svo_ring_submit_cams)"""
+        cams = np.ascontiguousarray(np.asarray(cams, dtype=np.float32).reshape(-1, 15))
+        fn = np.ascontiguousarray(np.asarray(frame_numbers, dtype=np.int32).reshape(-1))
+        assert cams.shape[0] == fn.size
+        slot = ctypes.c_int()
+        self._chk(self._L.svo_ring_submit_cams(self._h, int(fn.size), cams.ctypes.data, fn.ctypes.data, ctypes.byref(slot)))
         return int(slot.value)
 
     def ring_wait(self, slot):

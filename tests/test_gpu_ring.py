@@ -248,3 +248,61 @@ def test_large_batches_where_the_refill_reciprocal_is_inexact(ctx, w, h, spp, pe
         _eq(ctx.ring_read(s, k), want[k], hits=False)
     ctx.ring_destroy()
     ctx.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("pipeline", [1, 0, 2])
+def test_frames_with_their_own_cameras_in_flight(ctx, pipeline):
+    """svo_ring_submit_cams: 24 distinct cameras in flight (6 slots x 4 frames, one persistent launch per slot), the
+    camera path of a user who moves (Camera.rotate + strafe through the host mirror; frameNumber reset to 1 by the motion,
+    Main.java:225-233, 275) plus frames at rest in between (frameNumber counting on).  Every frame = svo_set_camera +
+    svo_dispatch of its own.  Through the JNI-typed export on the persistent pipeline."""
+    import ctypes
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS, orbit_path
+    w, h = 256, 144
+    cams, fns = orbit_path(24, yaw_step=0.02, pitch_step=0.003, forward=0.002, side=0.001)
+    fns = fns.copy()
+    cams[10:13] = cams[9]; fns[10:13] = [2, 3, 4]          # the user pauses for three frames
+    cams[23] = CAMERAS["K0"]; fns[23] = 77                  # and a cut to another camera
+    ctx.set_pipeline(pipeline)
+    ctx.set_tuning(10 if pipeline == 1 else 0, 9)
+    ctx.resize(w, h)
+    want = []
+    for k in range(24):
+        ctx.set_camera(cams[k])
+        want.append(_alone(ctx, w, h, int(fns[k]), 0))
+    ctx.set_camera(CAMERAS["K2"])                           # the context's own camera is not what the frames use ...
+    ctx.set_params(5, 0, 0, 0, 2, 0, 1)
+    ctx.ring_create(6, 4, want_hits=True)
+    slots = []
+    for b in range(6):
+        if pipeline == 1 and b % 2 == 0:
+            L = hiplib.lib()
+            fn = L.Java_src_engine_HipRenderer_nRingSubmitCams
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
+            fn.restype = ctypes.c_int32
+            cc = np.ascontiguousarray(cams[4 * b:4 * b + 4]); ff = np.ascontiguousarray(fns[4 * b:4 * b + 4])
+            slots.append(fn(None, None, ctx._h.value, 4, cc.ctypes.data, ff.ctypes.data))
+            cc[:] = 0; ff[:] = 0                            # the arrays were copied before the call returned
+        else:
+            slots.append(ctx.ring_submit_cams(cams[4 * b:4 * b + 4], fns[4 * b:4 * b + 4]))
+    assert slots == list(range(6))
+    for b in range(6):
+        ctx.ring_wait(b)
+        q = ctx.ring_query(b)
+        assert q["nframes"] == 4 and q["first_frame"] == int(fns[4 * b])
+        for k in range(4):
+            _eq(ctx.ring_read(b, k, want_hits=True), want[4 * b + k])
+    # ... and is still there afterwards, as is its frameNumber
+    _eq(_alone(ctx, w, h, 5, 0), ctx.render(None, w, h, CAMERAS["K2"], 5, 0))
+    # one frame per submission takes the plain path (beam pre-pass allowed), a batch with the beam is refused
+    ctx.set_params(5, 0, 0, 1, 2, 0, 1)
+    s = ctx.ring_submit_cams(cams[3:4], fns[3:4])
+    _eq(ctx.ring_read(s, 0, want_hits=False), want[3], hits=False)
+    with pytest.raises(Exception):
+        ctx.ring_submit_cams(cams[:2], fns[:2])
+    ctx.set_params(5, 0, 0, 0, 2, 0, 1)
+    ctx.ring_destroy()
+    ctx.set_tuning(0, 0)
+    ctx.set_camera(CAMERAS["K1"])
+    ctx.set_pipeline(1)

@@ -46,12 +46,13 @@ def _kernel(kernels, *parts):
     return kernels[hit[0]]
 
 
+@pytest.mark.parametrize("cams", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
-def test_descriptor_walk_zeroes_a_new_ray_s_stack_column(disassembly, mode):
+def test_descriptor_walk_zeroes_a_new_ray_s_stack_column(disassembly, mode, cams):
     """trav_loop2's POP reads {descriptor, t_max} of its level unconditionally (no pushed-levels mask): every ray must
     start on a zeroed column = the reference's zero-initialised octstack (svotrace.comp:227).  12 levels of 8 bytes per
     lane: six ds_write2st64_b64 (or twelve ds_write_b64) next to the loop's one PUSH (ds_write2_b32)."""
-    ins = _kernel(disassembly, "persist_kernelILi%dE" % mode, "DescWalk")
+    ins = _kernel(disassembly, "persist_kernelILi%dE" % mode, "DescWalkELb%d" % cams)
     levels = 2 * ins.count("ds_write2st64_b64") + ins.count("ds_write_b64")
     assert levels >= 12, {k: ins.count(k) for k in set(ins) if k.startswith("ds_")}
     assert ins.count("ds_write2_b32") >= 1   # the PUSH
@@ -61,6 +62,6 @@ def test_persistent_kernels_use_no_scratch_beyond_the_known_spills(disassembly):
     """a tripwire, not a target: the descriptor walk's mode-0 kernel must keep its traversal loop free of scratch traffic
     (spills live in round code only) -- a `scratch_` / `buffer_..._offen` spill inside the loop body would show up as a
     jump in these counts"""
-    ins = _kernel(disassembly, "persist_kernelILi0E", "DescWalk")
+    ins = _kernel(disassembly, "persist_kernelILi0E", "DescWalkELb0")
     spills = sum(1 for i in ins if i.startswith("scratch_"))
     assert spills < 120, spills
