@@ -110,6 +110,11 @@ int svo_pool_commit(svo_ctx *ctx);
  * svo_pool_upload; read it with svo_pool_download); *out_nbytes = its size.  SVO_E_TOOLARGE if it would not fit
  * signed 32-bit child pointers. */
 int svo_build_from_heightmap(svo_ctx *ctx, const uint16_t *height, const uint8_t *material, int n, uint64_t *out_nbytes);
+/* the same from the maps as Octree.constructCompleteOctree feeds them to the shader: raw 16-bit samples of the height PNG
+ * (stbi_load_16 -> r16ui image, Octree.java:208-216), which the shader scales itself -- heightSample = int(r / 65536.0 *
+ * 2048) (chunkgen-heightmap.comp:16-19) = r >> 5, pinned with the rest of the voxel rule by the reference shader's own runs
+ * (tests/golden/chunkgen_golden.npz: bytes >= 128 of the signed r8i material image survive as they are). */
+int svo_build_from_heightmap16(svo_ctx *ctx, const uint16_t *raw16, const uint8_t *material, int n, uint64_t *out_nbytes);
 /* replaces OctreeThread.run / Octree.constructInnerOctree (OctreeThread.java:20-23, Octree.java:511-670) for a dense
  * chunk of voxels, whatever produced them (the reference fills chunks from height maps or from 3-D noise,
  * chunkgen*.comp): voxels[x | y << log2 n | z << 2 log2 n] (Octree.java:110-112), 0 = empty, n a power of two in

@@ -34,6 +34,16 @@
  *                               (value 1 scatters, every other value reflects) and the unconditional scatter of :506 off
  *   render <prefix>             writes <prefix>.rgba  <prefix>.depth  [<prefix>.ptr]
  *
+ *
+ * Second mode -- the world builder's first stage:  llvmpipe_ref <chunkgen-heightmap.comp> chunkgen  < jobfile
+ * runs the reference's voxelisation shader (height map + material map -> a dense chunk of voxels) the way
+ * src/tests/WorldGenerator.java:24-37 and Octree.constructCompleteOctree (Octree.java:216, 229, 274-287) drive it:
+ * r8i 3-D image on unit 3, r16ui height image on unit 4 (glTexSubImage2D GL_RED_INTEGER / GL_UNSIGNED_SHORT), r8i
+ * material image on unit 5 (GL_RED_INTEGER / GL_BYTE), chunk origin in uniforms 1-3, chunk / 8 work groups per axis,
+ * read back with glGetTexImage(GL_TEXTURE_3D, GL_RED_INTEGER, GL_BYTE).
+ *   maps <n> <height file: n*n u16, [z][x]> <material file: n*n u8>
+ *   chunk <size> <ox> <oy> <oz> <out file>        size^3 bytes, [z][y][x]
+ *
  * Build: see oracle/Makefile (output goes to oracle/_ref/, git-ignored).
  */
 #define _GNU_SOURCE
@@ -101,6 +111,8 @@ GLF(PFNGLFINISHPROC, glFinish)
 GLF(PFNGLGETTEXIMAGEPROC, glGetTexImage)
 GLF(PFNGLGETERRORPROC, glGetError)
 GLF(PFNGLPIXELSTOREIPROC, glPixelStorei)
+GLF(PFNGLTEXSTORAGE3DPROC, glTexStorage3D)
+GLF(PFNGLTEXSUBIMAGE2DPROC, glTexSubImage2D)
 
 static void load_gl(void) {
   GLLOAD(PFNGLGETSTRINGPROC, glGetString);
@@ -135,6 +147,8 @@ static void load_gl(void) {
   GLLOAD(PFNGLGETTEXIMAGEPROC, glGetTexImage);
   GLLOAD(PFNGLGETERRORPROC, glGetError);
   GLLOAD(PFNGLPIXELSTOREIPROC, glPixelStorei);
+  GLLOAD(PFNGLTEXSTORAGE3DPROC, glTexStorage3D);
+  GLLOAD(PFNGLTEXSUBIMAGE2DPROC, glTexSubImage2D);
 }
 
 static char *read_file(const char *path, size_t *len) {
@@ -332,6 +346,74 @@ static void write_file(const char *prefix, const char *ext, const void *data, si
   fclose(f);
 }
 
+/* chunkgen-heightmap.comp, driven as WorldGenerator.java / Octree.constructCompleteOctree drive it (see the header) */
+static int chunkgen_jobs(GLuint prog) {
+  GLuint maps[2] = {0, 0};
+  int have_maps = 0;
+  char line[8192];
+  glPixelStorei(GL_PACK_ALIGNMENT, 1);
+  glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+  while (fgets(line, sizeof line, stdin)) {
+    char cmd[64], a[4096], b[4096];
+    if (sscanf(line, "%63s", cmd) != 1) continue;
+    if (!strcmp(cmd, "maps")) {
+      int n = 0;
+      if (sscanf(line, "%*s %d %4095s %4095s", &n, a, b) != 3 || n <= 0) { fprintf(stderr, "maps <n> <height> <material>\n"); return 2; }
+      size_t lh = 0, lm = 0;
+      char *hm = read_file(a, &lh), *mm = read_file(b, &lm);
+      if (lh != (size_t)n * n * 2 || lm != (size_t)n * n) { fprintf(stderr, "map sizes\n"); return 2; }
+      if (have_maps) glDeleteTextures(2, maps);
+      glGenTextures(2, maps);
+      glActiveTexture(GL_TEXTURE4);                       /* Renderer.add2DTexture(4, GL_R16UI, ...) + buffer2DTexture */
+      glBindTexture(GL_TEXTURE_2D, maps[0]);
+      glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+      glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+      glTexStorage2D(GL_TEXTURE_2D, 1, GL_R16UI, n, n);
+      glBindImageTexture(4, maps[0], 0, GL_TRUE, 0, GL_READ_WRITE, GL_R16UI);
+      glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, n, n, GL_RED_INTEGER, GL_UNSIGNED_SHORT, hm);
+      glActiveTexture(GL_TEXTURE5);                       /* Renderer.add2DTexture(5, GL_R8I, ...) + buffer2DTexture */
+      glBindTexture(GL_TEXTURE_2D, maps[1]);
+      glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+      glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+      glTexStorage2D(GL_TEXTURE_2D, 1, GL_R8I, n, n);
+      glBindImageTexture(5, maps[1], 0, GL_TRUE, 0, GL_READ_WRITE, GL_R8I);
+      glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, n, n, GL_RED_INTEGER, GL_BYTE, mm);
+      free(hm); free(mm);
+      have_maps = 1;
+    } else if (!strcmp(cmd, "chunk")) {
+      int c = 0, ox = 0, oy = 0, oz = 0;
+      if (sscanf(line, "%*s %d %d %d %d %4095s", &c, &ox, &oy, &oz, a) != 5 || c < 8 || (c & 7) || !have_maps) {
+        fprintf(stderr, "chunk <size %% 8 == 0> <ox> <oy> <oz> <out> (after maps)\n");
+        return 2;
+      }
+      GLuint vox = 0;
+      glGenTextures(1, &vox);
+      glActiveTexture(GL_TEXTURE3);                       /* Renderer.add3DTexture(3, GL_R8I, c, c, c) */
+      glBindTexture(GL_TEXTURE_3D, vox);
+      glTexParameteri(GL_TEXTURE_3D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+      glTexStorage3D(GL_TEXTURE_3D, 1, GL_R8I, c, c, c);
+      glBindImageTexture(3, vox, 0, GL_TRUE, 0, GL_WRITE_ONLY, GL_R8I);
+      glUseProgram(prog);
+      glUniform1i(1, ox);
+      glUniform1i(2, oy);
+      glUniform1i(3, oz);
+      glDispatchCompute((GLuint)(c / 8), (GLuint)(c / 8), (GLuint)(c / 8));
+      glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT);
+      glFinish();
+      size_t nb = (size_t)c * c * c;
+      void *out = malloc(nb);
+      glGetTexImage(GL_TEXTURE_3D, 0, GL_RED_INTEGER, GL_BYTE, out);   /* Renderer.get3DTextureData */
+      write_file(a, "", out, nb);
+      free(out);
+      GLenum e = glGetError();
+      if (e) fprintf(stderr, "GL error 0x%x after chunk %s\n", e, a);
+      glDeleteTextures(1, &vox);
+      fprintf(stderr, "chunk %d^3 at (%d, %d, %d) -> %s\n", c, ox, oy, oz, a);
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s shader.comp < jobs\n", argv[0]); return 2; }
   void *h = dlopen("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so", RTLD_NOW | RTLD_GLOBAL);
@@ -364,6 +446,7 @@ int main(int argc, char **argv) {
   fprintf(stderr, "GL_VERSION %s | %s\n", glGetString(GL_VERSION), glGetString(GL_RENDERER));
 
   char *src = read_file(argv[1], NULL);
+  if (argc > 2 && !strcmp(argv[2], "chunkgen")) return chunkgen_jobs(build_program(src));
   /* "raw": a probe shader of our own with the same bindings (tools/probes/), run as it is -- no in-memory patches */
   const int raw = argc > 2 && !strcmp(argv[2], "raw");
   GLuint prog_plain = build_program(src);

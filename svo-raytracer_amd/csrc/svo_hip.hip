@@ -368,6 +368,15 @@ int svo_build_from_heightmap(svo_ctx *c, const uint16_t *height, const uint8_t *
   return refresh_dword0(c);
 }
 
+int svo_build_from_heightmap16(svo_ctx *c, const uint16_t *raw16, const uint8_t *material, int n, uint64_t *out_nbytes) {
+  if (!c || !raw16 || !material) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap16: null map");
+  if (n < 8 || n > 8192 || (n & (n - 1))) return fail(c, SVO_E_INVALID, "svo_build_from_heightmap16: n must be a power of two in 8..8192");
+  // chunkgen-heightmap.comp:16-19: heightSample = int(r / 65536.0 * 2048) -- exact in float (two powers of two): r >> 5
+  std::vector<uint16_t> h((size_t)n * (size_t)n);
+  for (size_t i = 0; i < h.size(); i++) h[i] = (uint16_t)(raw16[i] >> 5);
+  return svo_build_from_heightmap(c, h.data(), material, n, out_nbytes);
+}
+
 int svo_build_from_voxels(svo_ctx *c, const uint8_t *voxels, int n, uint64_t *out_nbytes) {
   if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || !voxels) return fail(c, SVO_E_INVALID, "svo_build_from_voxels: null grid");

@@ -22,6 +22,7 @@ EXPORTS = [
     "svo_ring_read_depth", "svo_ring_read_hits", "svo_ring_read_pixel", "svo_ring_bind_slot", "svo_ring_device_ptrs",
     "svo_set_reserved_cus", "svo_pool_commit", "svo_ring_forward_slot", "svo_dev_alloc", "svo_dev_free", "svo_dev_read",
     "svo_ipc_export", "svo_ipc_open", "svo_ipc_close", "svo_set_sequence", "svo_ring_submit_cams",
+    "svo_build_from_heightmap16",
 ]
 
 
@@ -64,6 +65,7 @@ def lib(path=None):
         L.svo_pool_upload_device.argtypes = [vp, vp, u64]
         L.svo_build_from_heightmap.argtypes = [vp, vp, vp, ci, ctypes.POINTER(u64)]
         L.svo_build_from_voxels.argtypes = [vp, vp, ci, ctypes.POINTER(u64)]
+        L.svo_build_from_heightmap16.argtypes = [vp, vp, vp, ci, ctypes.POINTER(u64)]
         L.svo_bind_outputs.argtypes = [vp, vp, vp, vp]
         L.svo_pool_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
         L.svo_set_camera.argtypes = [vp, fp, fp, fp, fp, fp]
@@ -180,6 +182,16 @@ class HipContext:
         assert height.shape == (n, n) and material.shape == (n, n)
         nb = ctypes.c_uint64()
         self._chk(self._L.svo_build_from_heightmap(self._h, height.ctypes.data, material.ctypes.data, n, ctypes.byref(nb)))
+        return int(nb.value)
+
+    def build_from_heightmap16(self, raw16, material):
+        """the same from raw 16-bit height samples as the reference feeds them to its shader (svo_build_from_heightmap16)"""
+        raw16 = np.ascontiguousarray(raw16, dtype=np.uint16)
+        material = np.ascontiguousarray(material, dtype=np.uint8)
+        n = raw16.shape[0]
+        assert raw16.shape == (n, n) and material.shape == (n, n)
+        nb = ctypes.c_uint64()
+        self._chk(self._L.svo_build_from_heightmap16(self._h, raw16.ctypes.data, material.ctypes.data, n, ctypes.byref(nb)))
         return int(nb.value)
 
     def build_from_voxels(self, grid):

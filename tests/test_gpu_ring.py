@@ -281,7 +281,7 @@ def test_frames_with_their_own_cameras_in_flight(ctx, pipeline):
             fn = L.Java_src_engine_HipRenderer_nRingSubmitCams
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
             fn.restype = ctypes.c_int32
-            cc = np.ascontiguousarray(cams[4 * b:4 * b + 4]); ff = np.ascontiguousarray(fns[4 * b:4 * b + 4])
+            cc = cams[4 * b:4 * b + 4].copy(); ff = fns[4 * b:4 * b + 4].copy()
             slots.append(fn(None, None, ctx._h.value, 4, cc.ctypes.data, ff.ctypes.data))
             cc[:] = 0; ff[:] = 0                            # the arrays were copied before the call returned
         else:
