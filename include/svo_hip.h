@@ -297,6 +297,54 @@ int svo_ipc_export(svo_ctx *ctx, void *dptr, void *handle64);
 int svo_ipc_open(svo_ctx *ctx, const void *handle64, void **dptr);
 int svo_ipc_close(svo_ctx *ctx, void *dptr);
 
+/* ---- N GPUs of one node behind the boundary ----------------------------------------------------------------------
+ * SURVEY 8(b) Threading: "a context is single-threaded; one context per GPU; the multi-GPU driver owns 8 contexts" -- this
+ * is that driver, inside the library, for a host that is ONE process with one render thread (the reference's Java host).
+ * The path shards by screen tile: member r of n renders tile rows r, r + n, r + 2n, ... of every frame;
+ * behind each launch its packed stripes travel to member 0 (the frame owner) -- exchange 0: a peer copy enqueued on the
+ * member's own stream (SDMA over xGMI, no CU slots needed next to the persistent waves); exchange 1: one RCCL send /
+ * receive pair per member inside ncclGroupStart / End (librccl is loaded on demand) -- and the owner hands out whole
+ * frames in frame order.  The pool is replicated: one upload from the host, n - 1 peer copies.  Every call is made from
+ * the one host thread; results are byte-identical to a single context's.  `devices` may name a device more than once
+ * (how the tests run n = 2, 3, 8 on one GPU; RCCL refuses that, peer copies do not).
+ * Replaces, for n GPUs: Renderer.addSSBO / updateSSBO (pool), the uniforms of Main.java:267-285, Renderer.dispatchCompute
+ * (Main.java:285) and the glGetTexImage readbacks (Main.java:132-146). */
+typedef struct svo_group svo_group;
+int svo_group_create(const int *devices, int n, svo_group **out);
+int svo_group_destroy(svo_group *g);
+const char *svo_group_last_error(const svo_group *g);
+int svo_group_size(const svo_group *g);
+/* member i's context, for what is per GPU (svo_get_stats, svo_derived_info, svo_set_derived, ...); do not resize, bind,
+ * or submit through it */
+svo_ctx *svo_group_member(svo_group *g, int i);
+int svo_group_pool_upload(svo_group *g, const void *host, uint64_t nbytes);
+int svo_group_pool_update(svo_group *g, const void *host_base, uint64_t start, uint64_t end);
+int svo_group_pool_download(svo_group *g, void *host, uint64_t nbytes);
+int svo_group_build_from_heightmap(svo_group *g, const uint16_t *height, const uint8_t *material, int n, uint64_t *out_nbytes);
+int svo_group_set_camera(svo_group *g, const float pos[3], const float l1[3], const float l2[3], const float r1[3], const float r2[3]);
+int svo_group_set_params(svo_group *g, int frame_number, int render_mode, int buffer_end, int use_beam, int bounces,
+                         uint32_t mirror_mask, int spp);
+int svo_group_set_pipeline(svo_group *g, int pipeline);
+int svo_group_set_tuning(svo_group *g, int waves_per_cu, int round_threshold_sixteenths);
+int svo_group_set_progressive(svo_group *g, int enabled);
+int svo_group_set_sequence(svo_group *g, int nframes, int fresh);
+/* the size of the whole frame; every member renders its stripes of it */
+int svo_group_resize(svo_group *g, int width, int height);
+/* as svo_ring_*: `slots` submissions in flight of up to frames_per_slot frames each, on every member at once */
+int svo_group_ring_create(svo_group *g, int slots, int frames_per_slot, int want_hits, int exchange);
+int svo_group_ring_destroy(svo_group *g);
+int svo_group_ring_submit(svo_group *g, int frame_number, int nframes, int *slot);
+int svo_group_ring_submit_cams(svo_group *g, int nframes, const float *cams, const int *frame_numbers, int *slot);
+/* the slot's frames are complete on every member AND have reached the owner */
+int svo_group_ring_wait(svo_group *g, int slot);
+/* gpu_ms: the slowest member's launch */
+int svo_group_ring_query(svo_group *g, int slot, int *done, int *first_frame, int *nframes, float *gpu_ms);
+/* whole frames in frame order (the stripes de-interleaved on the way out) */
+int svo_group_ring_read_color(svo_group *g, int slot, int k, void *rgba8);
+int svo_group_ring_read_depth(svo_group *g, int slot, int k, float *depth);
+int svo_group_ring_read_hits(svo_group *g, int slot, int k, svo_hit *hits);
+int svo_group_ring_read_pixel(svo_group *g, int slot, int k, int x, int y, void *rgba8, float *depth, svo_hit *hit);
+
 /* ---- readback ------------------------------------------------------------------- */
 /* replaces glGetTexImage of image 0 (rgba8; row 0 = p.y = 0, bytes R,G,B,A) and
  * image 1 (r32f depth) (Main.java:132-146, svotrace.comp:726-727) */

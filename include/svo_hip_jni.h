@@ -109,6 +109,32 @@ jint Java_src_engine_HipRenderer_nRingReadPixel(void *env, void *cls, jlong ctx,
 jint Java_src_engine_HipRenderer_nRingBindSlot(void *env, void *cls, jlong ctx, jint slot, jlong color_dptr, jlong depth_dptr,
                                                jlong hits_dptr, jlong frame_stride);
 
+
+/* ---- N GPUs behind the boundary: svo_group_* (include/svo_hip.h).  nGroupCreate returns the handle (the group's address) or
+ * a negative status; devices_addr = n ints; nGroupSetCamera takes the 15 floats of Camera.getUniform(); nGroupLastError
+ * returns the address of a NUL-terminated string (MemoryUtil.memUTF8); nGroupMember a context handle for the per-GPU natives. */
+jlong Java_src_engine_HipRenderer_nGroupCreate(void *env, void *cls, jlong devices_addr, jint n);
+jint Java_src_engine_HipRenderer_nGroupDestroy(void *env, void *cls, jlong g);
+jlong Java_src_engine_HipRenderer_nGroupLastError(void *env, void *cls, jlong g);
+jlong Java_src_engine_HipRenderer_nGroupMember(void *env, void *cls, jlong g, jint i);
+jint Java_src_engine_HipRenderer_nGroupPoolUpload(void *env, void *cls, jlong g, jlong addr, jlong nbytes);
+jint Java_src_engine_HipRenderer_nGroupPoolUpdate(void *env, void *cls, jlong g, jlong base_addr, jlong start, jlong end);
+jint Java_src_engine_HipRenderer_nGroupSetCamera(void *env, void *cls, jlong g, jlong cam15_addr);
+jint Java_src_engine_HipRenderer_nGroupSetParams(void *env, void *cls, jlong g, jint frame_number, jint render_mode, jint buffer_end, jint use_beam, jint bounces, jint mirror_mask, jint spp);
+jint Java_src_engine_HipRenderer_nGroupSetTuning(void *env, void *cls, jlong g, jint waves_per_cu, jint thresh);
+jint Java_src_engine_HipRenderer_nGroupSetProgressive(void *env, void *cls, jlong g, jint enabled);
+jint Java_src_engine_HipRenderer_nGroupSetSequence(void *env, void *cls, jlong g, jint nframes, jint fresh);
+jint Java_src_engine_HipRenderer_nGroupResize(void *env, void *cls, jlong g, jint w, jint h);
+jint Java_src_engine_HipRenderer_nGroupRingCreate(void *env, void *cls, jlong g, jint slots, jint frames_per_slot, jint want_hits, jint exchange);
+jint Java_src_engine_HipRenderer_nGroupRingDestroy(void *env, void *cls, jlong g);
+jint Java_src_engine_HipRenderer_nGroupRingSubmit(void *env, void *cls, jlong g, jint frame_number, jint nframes);
+jint Java_src_engine_HipRenderer_nGroupRingSubmitCams(void *env, void *cls, jlong g, jint nframes, jlong cams_addr, jlong frame_numbers_addr);
+jint Java_src_engine_HipRenderer_nGroupRingWait(void *env, void *cls, jlong g, jint slot);
+jint Java_src_engine_HipRenderer_nGroupRingDone(void *env, void *cls, jlong g, jint slot, jlong ms_addr);
+jint Java_src_engine_HipRenderer_nGroupRingReadColor(void *env, void *cls, jlong g, jint slot, jint k, jlong addr);
+jint Java_src_engine_HipRenderer_nGroupRingReadDepth(void *env, void *cls, jlong g, jint slot, jint k, jlong addr);
+jint Java_src_engine_HipRenderer_nGroupRingReadPixel(void *env, void *cls, jlong g, jint slot, jint k, jint x, jint y, jlong rgba_addr, jlong depth_addr, jlong hit_addr);
+
 #ifdef __cplusplus
 }
 #endif

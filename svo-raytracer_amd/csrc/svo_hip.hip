@@ -85,6 +85,7 @@ struct svo_ctx {
     hipEvent_t fvar_copied = nullptr;
     // svo_ring_forward_slot: after every submission, src -> dst (a peer's memory) and the submission's number -> *fwd_flag
     const void *fwd_src = nullptr; void *fwd_dst = nullptr; uint64_t fwd_bytes = 0; void *fwd_flag = nullptr;
+    int fwd_dst_device = -1;      // >= 0: dst lives on that device of THIS process (svo_group_*): a peer copy
     uint32_t *seq_word = nullptr;
   };
   std::vector<void *> ipc_opened;
@@ -829,7 +830,12 @@ int svo_time_frames(svo_ctx *c, int warmup, int iters, float *ms) {
 
 
 // ---------------------------------------------------------------- frames in flight behind the boundary
+static int ring_create_impl(svo_ctx *c, int slots, int frames_per_slot, int want_hits, bool own_images);
 int svo_ring_create(svo_ctx *c, int slots, int frames_per_slot, int want_hits) {
+  return ring_create_impl(c, slots, frames_per_slot, want_hits, true);
+}
+// own_images = false: every slot will be bound to caller-owned buffers before its first submission (svo_group_*)
+static int ring_create_impl(svo_ctx *c, int slots, int frames_per_slot, int want_hits, bool own_images) {
   if (!c || slots < 1 || slots > 8 || frames_per_slot < 1 || frames_per_slot > 64)
     return fail(c, SVO_E_INVALID, "svo_ring_create: 1..8 slots of 1..64 frames");
   if (c->width <= 0 || c->height <= 0) return fail(c, SVO_E_INVALID, "svo_ring_create: svo_resize not called");
@@ -854,12 +860,12 @@ int svo_ring_create(svo_ctx *c, int slots, int frames_per_slot, int want_hits) {
                                : hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&s.e0);
     if (e == hipSuccess) e = hipEventCreate(&s.e1);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.color, n * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.depth, n * 4);
-    if (e == hipSuccess && want_hits) e = hipMalloc((void **)&s.hits, n * 16);
-    if (e == hipSuccess) e = hipMemset(s.color, 0, n * 4);
-    if (e == hipSuccess) e = hipMemset(s.depth, 0, n * 4);
-    if (e == hipSuccess && want_hits) e = hipMemset(s.hits, 0, n * 16);
+    if (e == hipSuccess && own_images) e = hipMalloc((void **)&s.color, n * 4);
+    if (e == hipSuccess && own_images) e = hipMalloc((void **)&s.depth, n * 4);
+    if (e == hipSuccess && own_images && want_hits) e = hipMalloc((void **)&s.hits, n * 16);
+    if (e == hipSuccess && own_images) e = hipMemset(s.color, 0, n * 4);
+    if (e == hipSuccess && own_images) e = hipMemset(s.depth, 0, n * 4);
+    if (e == hipSuccess && own_images && want_hits) e = hipMemset(s.hits, 0, n * 16);
     if (e != hipSuccess) {
       ring_free(c);
       return fail(c, SVO_E_HIP, std::string("svo_ring_create: ") + hipGetErrorString(e));
@@ -912,6 +918,7 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
   HIPCHK(c, hipSetDevice(c->device));
   const int si = (int)(c->ring_next % (unsigned)c->ring.size());
   svo_ctx::RingSlot &s = c->ring[(size_t)si];
+  if (!s.xcolor && !s.color) return fail(c, SVO_E_INVALID, std::string(who) + ": the slot has no images (bind it first)");
   // the dispatch state of the context, with this slot's stream, images and frame range swapped in
   struct Saved {
     hipStream_t stream; uint32_t *col; float *dep; uint4 *hit; bool ext; int batch; uint64_t stride; int frame; float cam[15];
@@ -952,7 +959,10 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
   if (e == hipSuccess && rc == SVO_OK && s.fwd_dst) {
     // the slot's frames travel to the frame owner behind the launch, on the same stream: a device-to-device copy (SDMA
     // between GPUs: no CU slot needed next to the persistent waves), then the submission's number into the owner's flag
-    e = hipMemcpyAsync(s.fwd_dst, s.fwd_src, s.fwd_bytes, hipMemcpyDeviceToDevice, s.stream);
+    if (s.fwd_dst_device >= 0 && s.fwd_dst_device != c->device)
+      e = hipMemcpyPeerAsync(s.fwd_dst, s.fwd_dst_device, s.fwd_src, c->device, s.fwd_bytes, s.stream);
+    else
+      e = hipMemcpyAsync(s.fwd_dst, s.fwd_src, s.fwd_bytes, hipMemcpyDeviceToDevice, s.stream);
     if (e == hipSuccess && s.fwd_flag) {
       e = hipMemsetD32Async((hipDeviceptr_t)s.seq_word, (int)(c->ring_next + 1u), 1, s.stream);
       if (e == hipSuccess) e = hipMemcpyAsync(s.fwd_flag, s.seq_word, 4, hipMemcpyDeviceToDevice, s.stream);
@@ -1084,6 +1094,8 @@ int svo_ring_forward_slot(svo_ctx *c, int slot, const void *src, void *dst, uint
   if (dst && (!src || nbytes == 0)) return fail(c, SVO_E_INVALID, "svo_ring_forward_slot: source and size required");
   HIPCHK(c, hipSetDevice(c->device));
   if (dst && !s->seq_word) HIPCHK(c, hipMalloc((void **)&s->seq_word, 4));
+  if (dst && !s->e2) HIPCHK(c, hipEventCreateWithFlags(&s->e2, hipEventDisableTiming));
+  s->fwd_dst_device = -1;
   s->fwd_src = dst ? src : nullptr; s->fwd_dst = dst; s->fwd_bytes = dst ? nbytes : 0; s->fwd_flag = dst ? flag : nullptr;
   return SVO_OK;
 }
@@ -1199,6 +1211,10 @@ int svo_output_device_ptrs(svo_ctx *c, void **color, void **depth, void **hits) 
   if (hits) *hits = c->d_hits;
   return SVO_OK;
 }
+
+}  // extern "C"
+#include "svo_group.hip.h"
+extern "C" {
 
 #ifdef SVO_STAMPS
 // diagnostic builds only: raw copy of the persistent pipeline's counter ring (8 sets x 256 B)

@@ -158,4 +158,67 @@ jint Java_src_engine_HipRenderer_nRingBindSlot(void *, void *, jlong ctx, jint s
 }
 #undef CTX
 
+// ---- N GPUs behind the boundary (svo_group_*): the handle is the group's address
+#define GRP(x) ((svo_group *)(intptr_t)(x))
+jlong Java_src_engine_HipRenderer_nGroupCreate(void *, void *, jlong devices_addr, jint n) {
+  svo_group *g = nullptr;
+  const int rc = svo_group_create((const int *)(intptr_t)devices_addr, n, &g);
+  return rc == SVO_OK ? (jlong)(intptr_t)g : (jlong)rc;   // the handle, or a negative status
+}
+jint Java_src_engine_HipRenderer_nGroupDestroy(void *, void *, jlong g) { return svo_group_destroy(GRP(g)); }
+jlong Java_src_engine_HipRenderer_nGroupLastError(void *, void *, jlong g) { return (jlong)(intptr_t)svo_group_last_error(GRP(g)); }
+jlong Java_src_engine_HipRenderer_nGroupMember(void *, void *, jlong g, jint i) { return (jlong)(intptr_t)svo_group_member(GRP(g), i); }
+jint Java_src_engine_HipRenderer_nGroupPoolUpload(void *, void *, jlong g, jlong addr, jlong nbytes) {
+  return nbytes < 0 ? SVO_E_INVALID : svo_group_pool_upload(GRP(g), (const void *)(intptr_t)addr, (uint64_t)nbytes);
+}
+jint Java_src_engine_HipRenderer_nGroupPoolUpdate(void *, void *, jlong g, jlong base_addr, jlong start, jlong end) {
+  return (start < 0 || end < 0) ? SVO_E_INVALID : svo_group_pool_update(GRP(g), (const void *)(intptr_t)base_addr, (uint64_t)start, (uint64_t)end);
+}
+jint Java_src_engine_HipRenderer_nGroupSetCamera(void *, void *, jlong g, jlong cam15_addr) {
+  const float *c = (const float *)(intptr_t)cam15_addr;
+  return c ? svo_group_set_camera(GRP(g), c, c + 3, c + 6, c + 9, c + 12) : SVO_E_INVALID;
+}
+jint Java_src_engine_HipRenderer_nGroupSetParams(void *, void *, jlong g, jint frame_number, jint render_mode, jint buffer_end,
+                                                 jint use_beam, jint bounces, jint mirror_mask, jint spp) {
+  return svo_group_set_params(GRP(g), frame_number, render_mode, buffer_end, use_beam, bounces, (uint32_t)mirror_mask, spp);
+}
+jint Java_src_engine_HipRenderer_nGroupSetTuning(void *, void *, jlong g, jint waves_per_cu, jint thresh) {
+  return svo_group_set_tuning(GRP(g), waves_per_cu, thresh);
+}
+jint Java_src_engine_HipRenderer_nGroupSetProgressive(void *, void *, jlong g, jint enabled) { return svo_group_set_progressive(GRP(g), enabled); }
+jint Java_src_engine_HipRenderer_nGroupSetSequence(void *, void *, jlong g, jint nframes, jint fresh) { return svo_group_set_sequence(GRP(g), nframes, fresh); }
+jint Java_src_engine_HipRenderer_nGroupResize(void *, void *, jlong g, jint w, jint h) { return svo_group_resize(GRP(g), w, h); }
+jint Java_src_engine_HipRenderer_nGroupRingCreate(void *, void *, jlong g, jint slots, jint frames_per_slot, jint want_hits, jint exchange) {
+  return svo_group_ring_create(GRP(g), slots, frames_per_slot, want_hits, exchange);
+}
+jint Java_src_engine_HipRenderer_nGroupRingDestroy(void *, void *, jlong g) { return svo_group_ring_destroy(GRP(g)); }
+jint Java_src_engine_HipRenderer_nGroupRingSubmit(void *, void *, jlong g, jint frame_number, jint nframes) {
+  int slot = -1;
+  const int rc = svo_group_ring_submit(GRP(g), frame_number, nframes, &slot);
+  return rc == SVO_OK ? slot : rc;
+}
+jint Java_src_engine_HipRenderer_nGroupRingSubmitCams(void *, void *, jlong g, jint nframes, jlong cams_addr, jlong frame_numbers_addr) {
+  int slot = -1;
+  const int rc = svo_group_ring_submit_cams(GRP(g), nframes, (const float *)(intptr_t)cams_addr, (const int *)(intptr_t)frame_numbers_addr, &slot);
+  return rc == SVO_OK ? slot : rc;
+}
+jint Java_src_engine_HipRenderer_nGroupRingWait(void *, void *, jlong g, jint slot) { return svo_group_ring_wait(GRP(g), slot); }
+jint Java_src_engine_HipRenderer_nGroupRingDone(void *, void *, jlong g, jint slot, jlong ms_addr) {
+  int done = 0;
+  const int rc = svo_group_ring_query(GRP(g), slot, &done, nullptr, nullptr, (float *)(intptr_t)ms_addr);
+  return rc == SVO_OK ? done : rc;
+}
+jint Java_src_engine_HipRenderer_nGroupRingReadColor(void *, void *, jlong g, jint slot, jint k, jlong addr) {
+  return svo_group_ring_read_color(GRP(g), slot, k, (void *)(intptr_t)addr);
+}
+jint Java_src_engine_HipRenderer_nGroupRingReadDepth(void *, void *, jlong g, jint slot, jint k, jlong addr) {
+  return svo_group_ring_read_depth(GRP(g), slot, k, (float *)(intptr_t)addr);
+}
+jint Java_src_engine_HipRenderer_nGroupRingReadPixel(void *, void *, jlong g, jint slot, jint k, jint x, jint y, jlong rgba_addr,
+                                                     jlong depth_addr, jlong hit_addr) {
+  return svo_group_ring_read_pixel(GRP(g), slot, k, x, y, (void *)(intptr_t)rgba_addr, (float *)(intptr_t)depth_addr,
+                                   (svo_hit *)(intptr_t)hit_addr);
+}
+#undef GRP
+
 }  // extern "C"

@@ -23,6 +23,12 @@ EXPORTS = [
     "svo_set_reserved_cus", "svo_pool_commit", "svo_ring_forward_slot", "svo_dev_alloc", "svo_dev_free", "svo_dev_read",
     "svo_ipc_export", "svo_ipc_open", "svo_ipc_close", "svo_set_sequence", "svo_ring_submit_cams",
     "svo_build_from_heightmap16",
+    "svo_group_create", "svo_group_destroy", "svo_group_last_error", "svo_group_size", "svo_group_member", "svo_group_pool_upload",
+    "svo_group_pool_update", "svo_group_pool_download", "svo_group_build_from_heightmap", "svo_group_set_camera",
+    "svo_group_set_params", "svo_group_set_pipeline", "svo_group_set_tuning", "svo_group_set_progressive", "svo_group_set_sequence",
+    "svo_group_resize", "svo_group_ring_create", "svo_group_ring_destroy", "svo_group_ring_submit", "svo_group_ring_submit_cams",
+    "svo_group_ring_wait", "svo_group_ring_query", "svo_group_ring_read_color", "svo_group_ring_read_depth",
+    "svo_group_ring_read_hits", "svo_group_ring_read_pixel",
 ]
 
 
@@ -118,8 +124,37 @@ def lib(path=None):
         L.svo_read_beam.argtypes = [vp, vp]
         L.svo_read_pixel.argtypes = [vp, ci, ci, vp, vp, vp]
         L.svo_output_device_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        # N GPUs behind the boundary (svo_group_*)
+        L.svo_group_create.argtypes = [ip, ci, ctypes.POINTER(vp)]
+        L.svo_group_destroy.argtypes = [vp]
+        L.svo_group_last_error.argtypes = [vp]
+        L.svo_group_last_error.restype = ctypes.c_char_p
+        L.svo_group_size.argtypes = [vp]
+        L.svo_group_member.argtypes = [vp, ci]
+        L.svo_group_member.restype = vp
+        L.svo_group_pool_upload.argtypes = [vp, vp, u64]
+        L.svo_group_pool_update.argtypes = [vp, vp, u64, u64]
+        L.svo_group_pool_download.argtypes = [vp, vp, u64]
+        L.svo_group_build_from_heightmap.argtypes = [vp, vp, vp, ci, ctypes.POINTER(u64)]
+        L.svo_group_set_camera.argtypes = [vp, fp, fp, fp, fp, fp]
+        L.svo_group_set_params.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.c_uint32, ci]
+        L.svo_group_set_pipeline.argtypes = [vp, ci]
+        L.svo_group_set_tuning.argtypes = [vp, ci, ci]
+        L.svo_group_set_progressive.argtypes = [vp, ci]
+        L.svo_group_set_sequence.argtypes = [vp, ci, ci]
+        L.svo_group_resize.argtypes = [vp, ci, ci]
+        L.svo_group_ring_create.argtypes = [vp, ci, ci, ci, ci]
+        L.svo_group_ring_destroy.argtypes = [vp]
+        L.svo_group_ring_submit.argtypes = [vp, ci, ci, ip]
+        L.svo_group_ring_submit_cams.argtypes = [vp, ci, vp, vp, ip]
+        L.svo_group_ring_wait.argtypes = [vp, ci]
+        L.svo_group_ring_query.argtypes = [vp, ci, ip, ip, ip, fp]
+        L.svo_group_ring_read_color.argtypes = [vp, ci, ci, vp]
+        L.svo_group_ring_read_depth.argtypes = [vp, ci, ci, vp]
+        L.svo_group_ring_read_hits.argtypes = [vp, ci, ci, vp]
+        L.svo_group_ring_read_pixel.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
         for n in EXPORTS:
-            if n != "svo_last_error":
+            if n not in ("svo_last_error", "svo_group_last_error", "svo_group_member"):
                 getattr(L, n).restype = ci
         _lib = _libs[path] = L
     return _lib
@@ -129,6 +164,134 @@ class SvoError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"svo error {code}: {msg}")
         self.code = code
+
+
+class HipGroup:
+    """N GPUs behind the C ABI (include/svo_hip.h, svo_group_*): one process, one thread; member r renders every n-th tile
+    row, member 0 owns the assembled frames.  `devices` may repeat a device (tests on one GPU)."""
+
+    def __init__(self, devices, lib_path=None):
+        self._L = lib(lib_path)
+        self._h = ctypes.c_void_p()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._L.svo_group_create(devs, len(devices), ctypes.byref(self._h))
+        if rc != 0:
+            raise SvoError(rc, "svo_group_create failed (no GPU / bad device index)")
+        self.n = len(devices)
+        self.width = self.height = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SvoError(rc, self._L.svo_group_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.svo_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def member(self, i):
+        """a HipContext view of member i (stats, descriptor table info); not to be closed"""
+        c = HipContext.__new__(HipContext)
+        c._L = self._L
+        c._h = ctypes.c_void_p(self._L.svo_group_member(self._h, int(i)))
+        c.width, c.height = self.width, self.height
+        c.close = lambda: None
+        return c
+
+    def pool_upload(self, pool):
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        self._chk(self._L.svo_group_pool_upload(self._h, pool.ctypes.data, pool.size))
+
+    def pool_update(self, pool, start, end):
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        self._chk(self._L.svo_group_pool_update(self._h, pool.ctypes.data, int(start), int(end)))
+
+    def pool_download(self, nbytes):
+        out = np.zeros(int(nbytes), dtype=np.uint8)
+        self._chk(self._L.svo_group_pool_download(self._h, out.ctypes.data, out.size))
+        return out
+
+    def build_from_heightmap(self, height, material):
+        height = np.ascontiguousarray(height, dtype=np.uint16)
+        material = np.ascontiguousarray(material, dtype=np.uint8)
+        nb = ctypes.c_uint64()
+        self._chk(self._L.svo_group_build_from_heightmap(self._h, height.ctypes.data, material.ctypes.data, height.shape[0], ctypes.byref(nb)))
+        return int(nb.value)
+
+    def set_camera(self, cam):
+        cam = np.ascontiguousarray(np.asarray(cam, dtype=np.float32).reshape(5, 3))
+        fp = ctypes.POINTER(ctypes.c_float)
+        self._chk(self._L.svo_group_set_camera(self._h, *[cam[i].ctypes.data_as(fp) for i in range(5)]))
+
+    def set_params(self, frame_number=2, render_mode=2, buffer_end=0, use_beam=0, bounces=2, mirror_mask=0, spp=1):
+        self._chk(self._L.svo_group_set_params(self._h, int(frame_number), int(render_mode), int(buffer_end), int(use_beam),
+                                               int(bounces), int(mirror_mask), int(spp)))
+
+    def set_pipeline(self, p):
+        self._chk(self._L.svo_group_set_pipeline(self._h, int(p)))
+
+    def set_tuning(self, waves_per_cu=0, round_threshold_sixteenths=0):
+        self._chk(self._L.svo_group_set_tuning(self._h, int(waves_per_cu), int(round_threshold_sixteenths)))
+
+    def set_progressive(self, on):
+        self._chk(self._L.svo_group_set_progressive(self._h, 1 if on else 0))
+
+    def set_sequence(self, nframes, fresh=True):
+        self._chk(self._L.svo_group_set_sequence(self._h, int(nframes), 1 if fresh else 0))
+
+    def resize(self, width, height):
+        self._chk(self._L.svo_group_resize(self._h, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def ring_create(self, slots, frames_per_slot=1, want_hits=False, exchange=0):
+        self._chk(self._L.svo_group_ring_create(self._h, int(slots), int(frames_per_slot), 1 if want_hits else 0, int(exchange)))
+
+    def ring_destroy(self):
+        self._chk(self._L.svo_group_ring_destroy(self._h))
+
+    def ring_submit(self, frame_number, nframes=1):
+        slot = ctypes.c_int()
+        self._chk(self._L.svo_group_ring_submit(self._h, int(frame_number), int(nframes), ctypes.byref(slot)))
+        return int(slot.value)
+
+    def ring_submit_cams(self, cams, frame_numbers):
+        cams = np.ascontiguousarray(np.asarray(cams, dtype=np.float32).reshape(-1, 15))
+        fn = np.ascontiguousarray(np.asarray(frame_numbers, dtype=np.int32).reshape(-1))
+        slot = ctypes.c_int()
+        self._chk(self._L.svo_group_ring_submit_cams(self._h, int(fn.size), cams.ctypes.data, fn.ctypes.data, ctypes.byref(slot)))
+        return int(slot.value)
+
+    def ring_wait(self, slot):
+        self._chk(self._L.svo_group_ring_wait(self._h, int(slot)))
+
+    def ring_query(self, slot):
+        done, first, n, ms = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_float()
+        self._chk(self._L.svo_group_ring_query(self._h, int(slot), ctypes.byref(done), ctypes.byref(first), ctypes.byref(n), ctypes.byref(ms)))
+        return {"done": bool(done.value), "first_frame": int(first.value), "nframes": int(n.value), "gpu_ms": float(ms.value)}
+
+    def ring_read(self, slot, k=0, want_hits=False):
+        out = {"rgba": np.zeros((self.height, self.width, 4), dtype=np.uint8),
+               "depth": np.zeros((self.height, self.width), dtype=np.float32)}
+        self._chk(self._L.svo_group_ring_read_color(self._h, int(slot), int(k), out["rgba"].ctypes.data))
+        self._chk(self._L.svo_group_ring_read_depth(self._h, int(slot), int(k), out["depth"].ctypes.data))
+        if want_hits:
+            out["hits"] = np.zeros((self.height, self.width), dtype=HIT_DTYPE)
+            self._chk(self._L.svo_group_ring_read_hits(self._h, int(slot), int(k), out["hits"].ctypes.data))
+        return out
+
+    def ring_read_pixel(self, slot, k, x, y, want_hit=True):
+        rgba = np.zeros(4, dtype=np.uint8)
+        depth = np.zeros(1, dtype=np.float32)
+        hit = np.zeros(1, dtype=HIT_DTYPE)
+        self._chk(self._L.svo_group_ring_read_pixel(self._h, int(slot), int(k), int(x), int(y), rgba.ctypes.data, depth.ctypes.data,
+                                                    hit.ctypes.data if want_hit else None))
+        return rgba, float(depth[0]), hit[0]
 
 
 class HipContext:

@@ -1,0 +1,199 @@
+"""N GPUs behind the C ABI (include/svo_hip.h, svo_group_*): one process, one host thread, n member contexts; member r renders
+every n-th tile row, its stripes travel to member 0 behind the launch (peer copies), member 0 hands out whole frames.  On a
+one-GPU box the same device is passed n times -- every line of the group's logic runs (stripes, chunk layout, forward copies,
+de-interleave, pool replication, lockstep submission); only the copies are device-local instead of over xGMI.  Frames must be
+bit-equal to the reference shader's goldens and to a single context's frames.  Driven through the JNI-typed exports where
+they exist (what HipRenderer.Group calls)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import compare_with_golden, golden_case, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, hits=True):
+    assert np.array_equal(a["rgba"], b["rgba"])
+    assert np.array_equal(a["depth"].view(np.uint32), b["depth"].view(np.uint32))
+    if hits:
+        assert a["hits"].tobytes() == b["hits"].tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_group_frames_equal_reference_shader_goldens(n):
+    from svo_raytracer_amd import hiplib
+    g = hiplib.HipGroup([0] * n)
+    try:
+        g.set_pipeline(1)
+        seen = 0
+        for name, poolkey in golden_cases():
+            gc = golden_case(name, poolkey)
+            if gc["w"] * gc["h"] < 64 * 48:
+                continue
+            g.pool_upload(gc["pool"])
+            g.resize(gc["w"], gc["h"])
+            g.set_camera(gc["cam"])
+            g.set_params(gc["frame"], gc["mode"], 0, 0, 2, 0, 1)
+            g.ring_create(2, 1, want_hits=True)
+            s = g.ring_submit(gc["frame"], 1)
+            res = g.ring_read(s, 0, want_hits=True)
+            bad = compare_with_golden(res, gc)
+            assert bad == {k: 0 for k in bad}, (name, n, bad)
+            seen += 1
+            if seen >= (37 if n in (2, 3) else 8):
+                break
+        assert seen >= 8
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_group_through_jni_typed_calls_full_hd(n):
+    """the benchmark's shape at 1080p on a 1024^3 scene: 3 submissions in flight x 4 frames, static camera, then a submission
+    of 4 frames with their own cameras, then a progressive sequence; pool replicated by the group; crosshair pick"""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS, orbit_path
+    L = hiplib.lib()
+    i32, i64 = ctypes.c_int32, ctypes.c_int64
+
+    def J(name, *args, res=i32):
+        f = getattr(L, "Java_src_engine_HipRenderer_" + name)
+        f.restype = res
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [i64 if tag == "L" else i32 for _, tag in args]   # jlong / jint
+        return f(None, None, *[int(a) for a, _ in args])
+
+    pool, _ = scene.build_scene(1024)
+    w, h = 1920, 1080
+    one = hiplib.HipContext(0)
+    one.set_pipeline(1)
+    one.set_tuning(10, 9)
+    cams, fns = orbit_path(4, yaw_step=0.03)
+    want = {f: one.render(pool if f == 2 else None, w, h, CAMERAS["K1"], f, 0) for f in range(2, 14)}
+    moved = []
+    for k in range(4):
+        one.set_camera(cams[k])
+        moved.append(one.render(None, w, h, None, int(fns[k]), 0))
+    one.set_camera(CAMERAS["K1"])
+    one.set_progressive(True)
+    one.set_sequence(6, fresh=True)
+    seq = one.render(None, w, h, None, 2, 0)
+    one.close()
+
+    devs = np.zeros(n, dtype=np.int32)
+    gh = J("nGroupCreate", (devs.ctypes.data, "L"), (n, "i"), res=i64)
+    assert gh > 0
+    G = (gh, "L")
+    try:
+        assert J("nGroupPoolUpload", G, (pool.ctypes.data, "L"), (pool.size, "L")) == 0
+        assert J("nGroupResize", G, (w, "i"), (h, "i")) == 0
+        cam = np.ascontiguousarray(CAMERAS["K1"], dtype=np.float32)
+        assert J("nGroupSetCamera", G, (cam.ctypes.data, "L")) == 0
+        assert J("nGroupSetParams", G, (2, "i"), (0, "i"), (0, "i"), (0, "i"), (2, "i"), (0, "i"), (1, "i")) == 0
+        assert J("nGroupSetTuning", G, (10, "i"), (9, "i")) == 0
+        assert J("nGroupRingCreate", G, (3, "i"), (4, "i"), (1, "i"), (0, "i")) == 0
+        slots = [J("nGroupRingSubmit", G, (2 + 4 * b, "i"), (4, "i")) for b in range(3)]
+        assert slots == [0, 1, 2]
+        rgba = np.zeros((h, w, 4), dtype=np.uint8)
+        depth = np.zeros((h, w), dtype=np.float32)
+        for b in range(3):
+            assert J("nGroupRingWait", G, (b, "i")) == 0
+            assert J("nGroupRingDone", G, (b, "i"), (0, "L")) == 1
+            for k in (0, 3):
+                assert J("nGroupRingReadColor", G, (b, "i"), (k, "i"), (rgba.ctypes.data, "L")) == 0
+                assert J("nGroupRingReadDepth", G, (b, "i"), (k, "i"), (depth.ctypes.data, "L")) == 0
+                _same({"rgba": rgba, "depth": depth}, want[2 + 4 * b + k], hits=False)
+        # the crosshair pick (Main.java:132-146) on a few pixels of frame 7 (slot 1, k 1), hit record included
+        hit = np.zeros(1, dtype=hiplib.HIT_DTYPE)
+        px4 = np.zeros(4, dtype=np.uint8)
+        d1 = np.zeros(1, dtype=np.float32)
+        for x, y in ((960, 540), (0, 0), (1919, 1079), (13, 8 * n + 3), (777, 8 * (n - 1) + 7)):
+            assert J("nGroupRingReadPixel", G, (1, "i"), (1, "i"), (x, "i"), (y, "i"), (px4.ctypes.data, "L"), (d1.ctypes.data, "L"),
+                     (hit.ctypes.data, "L")) == 0
+            assert np.array_equal(px4, want[7]["rgba"][y, x]) and d1.view(np.uint32)[0] == want[7]["depth"].view(np.uint32)[y, x]
+            assert hit[0].tobytes() == want[7]["hits"][y, x].tobytes()
+        # frames with their own cameras
+        cc, ff = np.ascontiguousarray(cams), np.ascontiguousarray(fns)
+        s = J("nGroupRingSubmitCams", G, (4, "i"), (cc.ctypes.data, "L"), (ff.ctypes.data, "L"))
+        assert s == 0
+        for k in range(4):
+            assert J("nGroupRingReadColor", G, (s, "i"), (k, "i"), (rgba.ctypes.data, "L")) == 0
+            assert J("nGroupRingReadDepth", G, (s, "i"), (k, "i"), (depth.ctypes.data, "L")) == 0
+            _same({"rgba": rgba, "depth": depth}, moved[k], hits=False)
+        # a progressive sequence (config 5's shape) across the members
+        assert J("nGroupSetProgressive", G, (1, "i")) == 0 and J("nGroupSetSequence", G, (6, "i"), (1, "i")) == 0
+        s = J("nGroupRingSubmit", G, (2, "i"), (1, "i"))
+        assert s == 1
+        assert J("nGroupRingReadColor", G, (s, "i"), (0, "i"), (rgba.ctypes.data, "L")) == 0
+        assert J("nGroupRingReadDepth", G, (s, "i"), (0, "i"), (depth.ctypes.data, "L")) == 0
+        _same({"rgba": rgba, "depth": depth}, seq, hits=False)
+        assert J("nGroupRingDestroy", G) == 0
+    finally:
+        assert J("nGroupDestroy", G) == 0
+
+
+def test_group_pool_updates_and_builder_reach_every_member():
+    """an SDF brush stroke's two byte ranges (Main.java:349-350) through svo_group_pool_update; the GPU builder on member 0 with
+    the pool replicated device to device"""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    n = 3
+    hmap, mmap = scene.scene_maps(256)
+    pool, _ = scene.build_scene(256)
+    one = hiplib.HipContext(0)
+    g = hiplib.HipGroup([0] * n)
+    try:
+        nb = g.build_from_heightmap(hmap, mmap)
+        assert nb == pool.size and np.array_equal(g.pool_download(nb), pool)
+        for r in range(n):
+            assert np.array_equal(g.member(r).pool_download(nb), pool)
+        w, h = 320, 200
+        g.resize(w, h)
+        g.set_camera(CAMERAS["K1"])
+        g.set_params(2, 2, 0, 0, 2, 0, 1)
+        g.ring_create(1, 1, want_hits=True)
+        edited = pool.copy()
+        root_cp = int.from_bytes(bytes(edited[1:5]), "big", signed=True)
+        edited[root_cp:root_cp + 7 * 8:7] ^= 1            # flip the value bytes of the root's children (records are 7 bytes: all interior)
+        g.pool_update(edited, root_cp, root_cp + 56)
+        s = g.ring_submit(2, 1)
+        got = g.ring_read(s, 0, want_hits=True)
+        _same(got, one.render(edited, w, h, CAMERAS["K1"], 2, 2))
+        assert g.ring_query(s)["done"] and g.ring_query(s)["gpu_ms"] > 0
+    finally:
+        g.close()
+        one.close()
+
+
+def test_group_rccl_exchange_loads_and_runs_at_one_member():
+    """exchange 1 = RCCL send / receive.  One GPU cannot host two RCCL ranks, so only what can run here does: librccl is
+    found, a one-member group renders; a group that repeats a device is refused by ncclCommInitAll with its message."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(128)
+    g = hiplib.HipGroup([0])
+    try:
+        g.pool_upload(pool)
+        g.resize(160, 96)
+        g.set_camera(CAMERAS["K1"])
+        g.set_params(2, 0, 0, 0, 2, 0, 1)
+        g.ring_create(2, 2, want_hits=False, exchange=1)
+        s = g.ring_submit(2, 2)
+        a = g.ring_read(s, 1)
+        one = hiplib.HipContext(0)
+        _same(a, one.render(pool, 160, 96, CAMERAS["K1"], 3, 0), hits=False)
+        one.close()
+    finally:
+        g.close()
+    g2 = hiplib.HipGroup([0, 0])
+    try:
+        g2.resize(160, 96)
+        with pytest.raises(hiplib.SvoError) as e:
+            g2.ring_create(2, 2, want_hits=False, exchange=1)
+        assert "nccl" in str(e.value).lower() or "rccl" in str(e.value).lower()
+    finally:
+        g2.close()
