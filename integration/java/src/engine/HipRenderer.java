@@ -304,6 +304,235 @@ public class HipRenderer {
     check(nSetStripes(ctx, firstTileRow, tileRowStep, nTileRows, outRow0));
   }
 
+  // ---- the rest of the C ABI, one thin method per native (what a host that drives the library directly needs) ---------
+  /** svo_destroy: frees every device resource of the context (the JVM's exit does it otherwise). */
+  public void destroy() {
+    check(nDestroy(ctx));
+    ctx = 0;
+  }
+
+  /** svo_dispatch_async / svo_sync: enqueue a frame and return; wait for it. */
+  public void dispatchAsync() {
+    check(nSetParams(ctx, frameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+    check(nDispatchAsync(ctx));
+  }
+
+  public void sync() {
+    check(nSync(ctx));
+  }
+
+  /** svo_set_stream: a caller-owned hipStream_t (0 = the library's own). */
+  public void setStream(long hipStream) {
+    check(nSetStream(ctx, hipStream));
+  }
+
+  /** svo_bind_outputs / svo_set_batch: caller-owned device images (device pointers), frames per dispatch. */
+  public void bindOutputs(long colorDevicePtr, long depthDevicePtr, long hitsDevicePtr) {
+    check(nBindOutputs(ctx, colorDevicePtr, depthDevicePtr, hitsDevicePtr));
+  }
+
+  public void setBatch(int nframes, long frameStride) {
+    check(nSetBatch(ctx, nframes, frameStride));
+  }
+
+  /** svo_ring_bind_slot: a ring slot renders into caller-owned device buffers (a rank's chunk of a gather buffer). */
+  public void bindFrameSlot(int slot, long colorDevicePtr, long depthDevicePtr, long hitsDevicePtr, long frameStride) {
+    check(nRingBindSlot(ctx, slot, colorDevicePtr, depthDevicePtr, hitsDevicePtr, frameStride));
+  }
+
+  /** hit records (16 bytes per pixel: pointer, normal | value | level, iterations, t) of frame k of a slot */
+  public void readFrameHits(int slot, int k, ByteBuffer hits) {
+    check(nRingReadHits(ctx, slot, k, MemoryUtil.memAddress(hits)));
+  }
+
+  /** the beam pre-pass image of the last frame dispatched with useBeamOptimization (ceil(H/4) x ceil(W/4) floats) */
+  public void readBeam(ByteBuffer beam) {
+    check(nReadBeam(ctx, MemoryUtil.memAddress(beam)));
+  }
+
+  public void setRows(int y0, int y1) {
+    check(nSetRows(ctx, y0, y1));
+  }
+
+  public void setHitRecords(boolean on) {
+    check(nSetHitRecords(ctx, on ? 1 : 0));
+  }
+
+  /** 0 = walk the pool's records as the shader does, 1 (default) = the interior-descriptor table when the pool allows */
+  public void setDerived(int mode) {
+    check(nSetDerived(ctx, mode));
+  }
+
+  /** descriptors of the interior-descriptor table (built if need be), or a negative status; walkable[0] = 1 if it is used */
+  public long derivedInfo(int[] walkable) {
+    ByteBuffer w = MemoryUtil.memAlloc(4);
+    long n = nDerivedInfo(ctx, MemoryUtil.memAddress(w));
+    if (walkable != null && walkable.length > 0)
+      walkable[0] = w.getInt(0);
+    MemoryUtil.memFree(w);
+    return n;
+  }
+
+  /** svo_count_frame / svo_get_stats into a 56-byte svo_stats (pixels, rays, nan rays, iterations, algorithmic bytes, ...) */
+  public void countFrame(ByteBuffer stats56) {
+    check(nSetParams(ctx, frameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+    check(nCountFrame(ctx, MemoryUtil.memAddress(stats56)));
+  }
+
+  public void getStats(ByteBuffer stats56) {
+    check(nGetStats(ctx, MemoryUtil.memAddress(stats56)));
+  }
+
+  // ---- N GPUs of one node (svo_group_*): the same calls, the work split by screen tile across the devices -------------
+  /**
+   * createGroup(new int[] {0, 1, ..., 7}): one process, this one render thread, n MI355X.  GPU r renders every n-th 8-pixel
+   * tile row of every frame; its stripes travel to GPU 0 over xGMI behind the launch (peer copies on the SDMA engines, or
+   * exchange = 1: RCCL send / receive); readFrame hands out whole frames.  The pool is uploaded once and replicated device
+   * to device.  Same results, byte for byte, as the single-GPU renderer.
+   */
+  public static Group createGroup(int[] devices) {
+    ByteBuffer d = MemoryUtil.memAlloc(4 * devices.length);
+    for (int i = 0; i < devices.length; i++)
+      d.putInt(4 * i, devices[i]);
+    long h = nGroupCreate(MemoryUtil.memAddress(d), devices.length);
+    MemoryUtil.memFree(d);
+    if (h <= 0) {
+      System.out.println("HIP ERR: svo_group_create status " + h);
+      return null;
+    }
+    return new Group(h, devices.length);
+  }
+
+  public static class Group {
+    private long g;
+    private final int size;
+    private int renderMode = 2, bufferEnd = 0, useBeam = 0, bounces = 2, mirrorMask = 0, spp = 1;
+
+    Group(long handle, int n) {
+      g = handle;
+      size = n;
+    }
+
+    private void check(int rc) {
+      if (rc != 0)
+        System.out.println("HIP ERR: " + MemoryUtil.memUTF8(nGroupLastError(g)));   // print and go on, as Renderer does
+    }
+
+    public int size() {
+      return size;
+    }
+
+    /** Renderer.addSSBO: the whole pool, once from the host, then GPU to GPU. */
+    public void addSSBO(int bindIndex, ByteBuffer data) {
+      check(nGroupPoolUpload(g, MemoryUtil.memAddress(data), data.remaining()));
+    }
+
+    /** Renderer.updateSSBO(bindIndex, data, start, end): a brush stroke's byte range, to every GPU. */
+    public void updateSSBO(int bindIndex, ByteBuffer data, int start, int end) {
+      check(nGroupPoolUpdate(g, MemoryUtil.memAddress0(data), start, end));
+    }
+
+    public void setImageSize(int width, int height) {
+      check(nGroupResize(g, width, height));
+    }
+
+    /** Camera.getUniform(): pos, l1, l2, r1, r2 (Main.java:269-273). */
+    public void setCamera(float[][] u) {
+      ByteBuffer c = MemoryUtil.memAlloc(60);
+      for (int v = 0; v < 5; v++)
+        for (int i = 0; i < 3; i++)
+          c.putFloat(4 * (3 * v + i), u[v][i]);
+      check(nGroupSetCamera(g, MemoryUtil.memAddress(c)));
+      MemoryUtil.memFree(c);
+    }
+
+    public void setFrameParams(int renderMode, int bufferEnd, boolean useBeam) {
+      this.renderMode = renderMode;
+      this.bufferEnd = bufferEnd;
+      this.useBeam = useBeam ? 1 : 0;
+    }
+
+    public void setPathOptions(int bounces, int mirrorMask, int spp) {
+      this.bounces = bounces;
+      this.mirrorMask = mirrorMask;
+      this.spp = spp;
+    }
+
+    public void setTuning(int wavesPerCu, int roundThresholdSixteenths) {
+      check(nGroupSetTuning(g, wavesPerCu, roundThresholdSixteenths));
+    }
+
+    public void setProgressive(boolean on, int framesPerDispatch, boolean fresh) {
+      check(nGroupSetProgressive(g, on ? 1 : 0));
+      check(nGroupSetSequence(g, framesPerDispatch, fresh ? 1 : 0));
+    }
+
+    public void createFrameRing(int slots, int framesPerSlot, boolean wantHits, int exchange) {
+      check(nGroupRingCreate(g, slots, framesPerSlot, wantHits ? 1 : 0, exchange));
+    }
+
+    public void destroyFrameRing() {
+      check(nGroupRingDestroy(g));
+    }
+
+    /** frames firstFrameNumber .. + nframes - 1 of the current camera on every GPU; returns the slot or a negative status */
+    public int submitFrames(int firstFrameNumber, int nframes) {
+      check(nGroupSetParams(g, firstFrameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+      return nGroupRingSubmit(g, firstFrameNumber, nframes);
+    }
+
+    /** frames with their own cameras (float[15] each) and frame numbers */
+    public int submitFrames(float[][] cams, int[] frameNumbers) {
+      int n = frameNumbers.length;
+      check(nGroupSetParams(g, frameNumbers[0], renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+      ByteBuffer c = MemoryUtil.memAlloc(60 * n), f = MemoryUtil.memAlloc(4 * n);
+      for (int k = 0; k < n; k++) {
+        for (int i = 0; i < 15; i++)
+          c.putFloat(60 * k + 4 * i, cams[k][i]);
+        f.putInt(4 * k, frameNumbers[k]);
+      }
+      int slot = nGroupRingSubmitCams(g, n, MemoryUtil.memAddress(c), MemoryUtil.memAddress(f));
+      MemoryUtil.memFree(c);
+      MemoryUtil.memFree(f);
+      return slot;
+    }
+
+    public void awaitFrames(int slot) {
+      check(nGroupRingWait(g, slot));
+    }
+
+    public boolean framesDone(int slot) {
+      return nGroupRingDone(g, slot, 0L) == 1;
+    }
+
+    /** glGetTexImage of image 0 / image 1 for frame k of a slot: whole frames, rows in frame order. */
+    public void readFrame(int slot, int k, ByteBuffer rgba8, ByteBuffer depth) {
+      if (rgba8 != null)
+        check(nGroupRingReadColor(g, slot, k, MemoryUtil.memAddress(rgba8)));
+      if (depth != null)
+        check(nGroupRingReadDepth(g, slot, k, MemoryUtil.memAddress(depth)));
+    }
+
+    /** The crosshair pick of Main.java:132-146. */
+    public float readFrameDepthPixel(int slot, int k, int x, int y) {
+      ByteBuffer one = MemoryUtil.memAlloc(4);
+      check(nGroupRingReadPixel(g, slot, k, x, y, 0L, MemoryUtil.memAddress(one), 0L));
+      float d = one.getFloat(0);
+      MemoryUtil.memFree(one);
+      return d;
+    }
+
+    /** member i's context handle (svo_group_member), for the per-GPU natives: statistics, descriptor-table information */
+    public long memberContext(int i) {
+      return nGroupMember(g, i);
+    }
+
+    public void destroy() {
+      check(nGroupDestroy(g));
+      g = 0;
+    }
+  }
+
   private void check(int rc) {
     if (rc != 0)
       printGLErrors();
@@ -357,4 +586,26 @@ public class HipRenderer {
   private static native int nRingReadPixel(long ctx, int slot, int k, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);
   private static native int nRingBindSlot(long ctx, int slot, long colorDevicePtr, long depthDevicePtr, long hitsDevicePtr,
       long frameStride);
+  private static native long nGroupCreate(long devicesAddr, int n);
+  private static native int nGroupDestroy(long g);
+  private static native long nGroupLastError(long g);
+  private static native long nGroupMember(long g, int i);
+  private static native int nGroupPoolUpload(long g, long addr, long nbytes);
+  private static native int nGroupPoolUpdate(long g, long baseAddr, long start, long end);
+  private static native int nGroupSetCamera(long g, long cam15Addr);
+  private static native int nGroupSetParams(long g, int frameNumber, int renderMode, int bufferEnd, int useBeam, int bounces,
+      int mirrorMask, int spp);
+  private static native int nGroupSetTuning(long g, int wavesPerCu, int roundThresholdSixteenths);
+  private static native int nGroupSetProgressive(long g, int enabled);
+  private static native int nGroupSetSequence(long g, int nframes, int fresh);
+  private static native int nGroupResize(long g, int width, int height);
+  private static native int nGroupRingCreate(long g, int slots, int framesPerSlot, int wantHits, int exchange);
+  private static native int nGroupRingDestroy(long g);
+  private static native int nGroupRingSubmit(long g, int frameNumber, int nframes);
+  private static native int nGroupRingSubmitCams(long g, int nframes, long camsAddr, long frameNumbersAddr);
+  private static native int nGroupRingWait(long g, int slot);
+  private static native int nGroupRingDone(long g, int slot, long msAddr);
+  private static native int nGroupRingReadColor(long g, int slot, int k, long addr);
+  private static native int nGroupRingReadDepth(long g, int slot, int k, long addr);
+  private static native int nGroupRingReadPixel(long g, int slot, int k, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);
 }

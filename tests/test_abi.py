@@ -43,3 +43,30 @@ def test_no_silent_cpu_fallback_without_gpu():
     h = ctypes.c_void_p()
     assert L.svo_create(0, ctypes.byref(h)) == -4  # SVO_E_NODEVICE
     assert not h.value
+
+
+def test_java_twin_natives_match_the_jni_header():
+    """No JDK in the image: HipRenderer.java has never met a compiler.  What can be checked mechanically is: every `native`
+    method it declares has an export in include/svo_hip_jni.h (and in the library) with the same number of parameters and
+    the matching primitive types (int <-> jint, long <-> jlong, float <-> jfloat), and every export has a declaration."""
+    L = hiplib.lib()
+    java = open(os.path.join(ROOT, "integration", "java", "src", "engine", "HipRenderer.java")).read()
+    hdr = open(os.path.join(ROOT, "include", "svo_hip_jni.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    jmap = {"int": "jint", "long": "jlong", "float": "jfloat"}
+    natives = {}
+    for ret, name, params in re.findall(r"private static native (\w+) (n\w+)\(([^)]*)\);", java):
+        types = [p.split()[0] for p in params.split(",") if p.strip()]
+        natives[name] = (jmap[ret], [jmap[t] for t in types])
+    exports = {}
+    for ret, name, params in re.findall(r"\b(j\w+) Java_src_engine_HipRenderer_(n\w+)\(([^)]*)\);", hdr):
+        types = [p.split()[0] for p in params.split(",")][2:]     # after env, cls
+        exports[name] = (ret, types)
+    assert len(natives) >= 60
+    assert sorted(natives) == sorted(exports), (sorted(set(natives) - set(exports)), sorted(set(exports) - set(natives)))
+    for name, sig in natives.items():
+        assert sig == exports[name], (name, sig, exports[name])
+        assert hasattr(L, "Java_src_engine_HipRenderer_" + name), name
+    # and every native is used by some method of the twin (no dead declarations)
+    for name in natives:
+        assert len(re.findall(r"\b%s\(" % name, java)) >= 2, name
