@@ -68,8 +68,15 @@ PRESETS = {
     "C2": dict(size=2048, width=1920, height=1080, mode=1, bounces=2, mirror=0, spp=1),
     "C3": dict(size=8192, width=1920, height=1080, mode=0, bounces=2, mirror=0, spp=1),
     "C4": dict(size=8192, width=3840, height=2160, mode=0, bounces=5, mirror=0b1000, spp=1),
-    "C5": dict(size=8192, width=1920, height=1080, mode=0, bounces=2, mirror=0, spp=64),
+    # C5 "64 spp accumulated GI" in the reference's own terms: the cross-frame accumulation of svotrace.comp:712-719 over
+    # 64 frames (frameNumber 2..65 on a fresh image, Main.java:16,275); a step = one such 64-frame sequence (svo_set_sequence)
+    "C5": dict(size=8192, width=1920, height=1080, mode=0, bounces=2, mirror=0, spp=1, seq=64),
+    # the library's own reading of the shader's commented-out SAMPLES loop (:668-670): 64 samples per frame, seeds
+    # frameNumber + sample, fp32 mean -- HIP <-> oracle only, no reference behaviour
+    "C5spp": dict(size=8192, width=1920, height=1080, mode=0, bounces=2, mirror=0, spp=64, seq=1),
 }
+for _p in PRESETS.values():
+    _p.setdefault("seq", 1)
 
 
 def parse(argv=None):
@@ -85,7 +92,18 @@ def parse(argv=None):
     ap.add_argument("--bounces", type=int, default=None, help="path segments in mode 0 (2 = primary + 1 bounce)")
     ap.add_argument("--mirror", type=lambda v: int(v, 0), default=None, help="bit mask of mirror materials (svotrace.comp:500-504)")
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel accumulated per frame (svotrace.comp:668-670)")
+    ap.add_argument("--seq", type=int, default=None, help="frames of the cross-frame accumulation (svotrace.comp:712-719) per step: "
+                                                          "one step = frameNumber 2 .. seq + 1 blended into one image (svo_set_sequence)")
     ap.add_argument("--camera", default="K1")
+    ap.add_argument("--camera-path", choices=["static", "orbit"], default="static",
+                    help="orbit: every timed frame carries its own camera (Camera.rotate + strafe through the host mirror) and "
+                         "frameNumber 1 (Main resets it on motion, Main.java:225-233, 275): svo_ring_submit_cams")
+    ap.add_argument("--moving", type=int, default=1, help="also measure the default configuration with a moving camera "
+                                                          "(value_moving_camera; one GPU, static runs only)")
+    ap.add_argument("--long-steps", type=int, default=400, help="N > 1: steps of the second, longer timed region (value_long_run)")
+    ap.add_argument("--driver", choices=["torch", "group"], default="torch",
+                    help="N > 1: torch = one process per GPU under torch.distributed (RCCL gather or IPC copies); group = ONE "
+                         "process, the N GPUs behind the C ABI (svo_group_*: peer copies or RCCL send / receive inside the library)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SVO_BENCH_PIPELINE", "1")),
                     help="0 one thread per pixel, 1 persistent waves (default), 2 staged wavefront")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
@@ -178,7 +196,7 @@ def source_hash():
 def default_batch(args, world):
     """Frames per dispatch when --batch is not given: several samples per pixel already make one dispatch a long launch
     (the library folds them into it), so such frames go one per dispatch."""
-    if args.spp > 1:
+    if args.spp > 1 or args.seq > 1:
         return 1
     return DEFAULT_BATCH.get(world, 4 if world > 8 else 1)
 
@@ -186,6 +204,10 @@ def default_batch(args, world):
 def pmc_key(args, width, height, nbuf, batch):
     """What a set of per-launch PMC figures belongs to (tools/pmc_pass.py writes under the same key)."""
     key = "%s_%dx%d_m%d_b%d_s%d_p%d_if%d" % (args.size, width, height, args.mode, args.bounces, args.spp, args.pipeline, nbuf)
+    if args.seq > 1:
+        key += "_seq%d" % args.seq
+    if args.camera_path != "static":
+        key += "_" + args.camera_path
     if batch > 1:
         key += "_B%d" % batch
     if args.beam:
@@ -218,7 +240,8 @@ def main(argv=None, ctx_factory=None):
     args = parse(argv)
     stub = ctx_factory is not None
     dev = "cpu" if stub else "cuda"
-    if args.gpus > 1 and "RANK" not in os.environ:
+    group_mode = args.driver == "group" and "RANK" not in os.environ
+    if args.gpus > 1 and "RANK" not in os.environ and not group_mode:
         sys.exit(launch_ranks(args))
     # the dispatches in flight, the gather and torch's own stream each want a hardware queue of their own; HIP's default
     # of 4 makes two of the frame streams share one (their launches then serialise).  Read when the runtime starts.
@@ -255,11 +278,18 @@ def main(argv=None, ctx_factory=None):
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
     from svo_raytracer_amd.cameras import CAMERAS
-    from svo_raytracer_amd.framering import FrameRing, replicate_pool
+    from svo_raytracer_amd.framering import FrameRing, GroupAsContext, GroupRing, replicate_pool
 
     W, H = args.width, args.height
     cam = CAMERAS[args.camera]
-    ctx = ctx_factory(local_rank) if stub else hiplib.HipContext(local_rank)
+    # ngpu: GPUs that share a frame -- the ranks of the torch driver, or the members of ONE process's group (svo_group_*)
+    ngpu = args.gpus if group_mode else world
+    group = None
+    if group_mode:
+        group = hiplib.HipGroup([0] * ngpu if one_gpu else list(range(ngpu)))
+        ctx = GroupAsContext(group)
+    else:
+        ctx = ctx_factory(local_rank) if stub else hiplib.HipContext(local_rank)
 
     # ---- scene: built once on rank 0 (height / material maps on the host cores, the pool on the GPU by
     # svo_build_from_heightmap), replicated by one RCCL broadcast ------------------------------------------
@@ -284,13 +314,15 @@ def main(argv=None, ctx_factory=None):
         t_build = time.time() - t_build
 
     # ---- frame state -----------------------------------------------------------------------------
-    H_total = H * world if args.scaling == "weak" else H
+    H_total = H * ngpu if args.scaling == "weak" else H
     as_rank = tuple(int(v) for v in args.as_rank.split("/")) if args.as_rank else None
     ctx.resize(W, H_total)
     ctx.set_camera(cam)
     ctx.set_pipeline(args.pipeline)
     nbuf = min(8, max(2 if (use_comm or world > 1) else 1, args.inflight))
-    batch = args.batch if args.batch > 0 else default_batch(args, world if as_rank is None else as_rank[1])
+    batch = args.batch if args.batch > 0 else default_batch(args, ngpu if as_rank is None else as_rank[1])
+    if args.seq > 1:
+        batch = 1      # a step is a whole sequence: one submission, one image
     waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
     if args.pipeline == 1:
         ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and
@@ -304,9 +336,20 @@ def main(argv=None, ctx_factory=None):
     ctx.set_reserved_cus(comm_cus)
     params = dict(render_mode=args.mode, buffer_end=nbytes, use_beam=args.beam, bounces=args.bounces,
                   mirror_mask=args.mirror, spp=args.spp)
-    ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device=dev,
-                     dist=dist if (use_comm or world > 1) else None, want_hits=bool(args.hits), force_comm=force_comm,
-                     first_frame=2, params=params, as_rank=as_rank, batch=batch, exchange=args.exchange)
+    if group_mode:
+        ctx.set_params(2, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
+        ring = GroupRing(group, W, H_total, nbuf=nbuf, want_hits=bool(args.hits), first_frame=2, batch=batch,
+                         exchange=args.exchange, advance=args.seq == 1)
+    else:
+        ring = FrameRing(ctx, W, H_total, world=world, rank=rank, nbuf=nbuf, device=dev,
+                         dist=dist if (use_comm or world > 1) else None, want_hits=bool(args.hits), force_comm=force_comm,
+                         first_frame=2, params=params, as_rank=as_rank, batch=batch, exchange=args.exchange,
+                         advance=args.seq == 1)
+    # a camera that moves: every frame of the run carries its own camera and frameNumber (svo_ring_submit_cams)
+    path = None
+    if args.camera_path == "orbit":
+        from svo_raytracer_amd.cameras import orbit_path
+        path = orbit_path(args.warmup + args.steps + 8, start=args.camera)
 
     # ---- ray count (untimed counting pass of the first and the last timed frame) ---------------------
     def count(frame):    # on the context's own stream and images (the ring's slots are not involved)
@@ -316,16 +359,38 @@ def main(argv=None, ctx_factory=None):
 
     first_timed = 2 + args.warmup
     last_timed = first_timed + args.steps - 1
-    # every timed frame of a short run; of a long one, nine frames spread over it (first and last included)
-    counted = list(range(first_timed, last_timed + 1)) if args.steps <= 40 else \
-        sorted({first_timed + (args.steps - 1) * i // 8 for i in range(9)})
-    cs = [count(fr) for fr in counted]
-    keys = ("rays", "iterations", "alg_bytes", "pixels", "nan_rays")
-    mine = [sum(c[k] for c in cs) / float(len(cs)) for k in keys]
+    if args.seq > 1:
+        # a step renders frameNumber 2 .. seq + 1: its rays are those of all of them (same primaries, new bounces per frame)
+        cs = [count(fr) for fr in range(2, 2 + args.seq)]
+        keys = ("rays", "iterations", "alg_bytes", "pixels", "nan_rays")
+        mine = [float(sum(c[k] for c in cs)) for k in keys]
+    elif path is not None:
+        # every timed frame has its own camera: count nine of them (all of a short run)
+        idx = list(range(args.warmup, args.warmup + args.steps)) if args.steps <= 40 else \
+            sorted({args.warmup + (args.steps - 1) * i // 8 for i in range(9)})
+        cs = []
+        for i in idx:
+            ctx.set_camera(path[0][i])
+            cs.append(count(int(path[1][i])))
+        ctx.set_camera(cam)
+        keys = ("rays", "iterations", "alg_bytes", "pixels", "nan_rays")
+        mine = [sum(c[k] for c in cs) / float(len(cs)) for k in keys]
+    else:
+        # every timed frame of a short run; of a long one, nine frames spread over it (first and last included)
+        counted = list(range(first_timed, last_timed + 1)) if args.steps <= 40 else \
+            sorted({first_timed + (args.steps - 1) * i // 8 for i in range(9)})
+        cs = [count(fr) for fr in counted]
+        keys = ("rays", "iterations", "alg_bytes", "pixels", "nan_rays")
+        mine = [sum(c[k] for c in cs) / float(len(cs)) for k in keys]
     counts = torch.tensor(mine, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(counts)
     rays, iters, alg_bytes, pixels, nan_rays = [float(v) for v in counts.tolist()]
+    if args.seq > 1:
+        ctx.set_progressive(True)
+        ctx.set_sequence(args.seq, True)
+    if path is not None:
+        ring.start_path(*path)
 
     def run_frames(n):      # exactly n frames: whole batches, then a partial one
         while n > 0:
@@ -333,56 +398,118 @@ def main(argv=None, ctx_factory=None):
             ring.step(k)
             n -= k
 
+    def timed(nsteps):
+        """exactly nsteps steps between barrier + synchronize on both sides; returns this rank's seconds"""
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        run_frames(nsteps)
+        if group_mode:
+            ring.drain()      # every member's device, not only the current one
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        return time.perf_counter() - t0
+
     run_frames(args.warmup)
-    if world > 1:
-        dist.barrier()
-    sync()
     ring.timing = True
-    t0 = time.perf_counter()
-    run_frames(args.steps)
-    sync()
+    elapsed = timed(args.steps)
     ring.timing = False
-    if world > 1:
-        dist.barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
     rank_ms = [elapsed / args.steps * 1e3]     # every rank's own ms per step: min / max go on the line next to the MAX that counts
     if world > 1:
         tall = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
         dist.all_gather(tall, torch.tensor([elapsed], dtype=torch.float64, device=dev))
         rank_ms = [float(t.item()) / args.steps * 1e3 for t in tall]
         elapsed = max(float(t.item()) for t in tall)
+    # N > 1: a driver's 20-step region is 1.5 ms of work per rank at N = 8 -- all start and drain, and millisecond stalls of a
+    # box do not average out (DESIGN.md section 5).  The same protocol again over a longer region, as an extra key.
+    long_run = None
+    if (world > 1 or (group_mode and ngpu > 1)) and args.long_steps > 0 and args.seq == 1:
+        ring.drain()
+        el = timed(args.long_steps)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        long_run = (args.long_steps, el)
 
     # ---- the frames the ring still holds: the last nbuf timed frames, rendered with nbuf launches in flight ----
     ring.drain()
-    verified, vinfo = None, None
-    if args.verify and rank == 0:
+
+    def verify_ring(first_ok):
+        """Every dispatch the ring still holds (its first and its last frame), a pixel subsample of each, bit for bit against
+        the CPU oracle -- with the frame's own camera on a camera path, and through the oracle's statement of the cross-frame
+        accumulation (svotrace.comp:712-719) for progressive sequences.  Returns (ok, description)."""
         from oracle import oracle   # the checker; never on the timed path
         step = 16 if W * H_total <= 1920 * 1080 * 2 else 32
-        if args.spp > 8:
+        if args.spp > 8 or args.seq > 1:
             step *= 4
         rows_ok = ring.rendered_rows_mask().numpy()
         bad, npx, frames = 0, 0, []
-        # of every dispatch the ring still holds: its first and its last frame (timed ones only)
         held = sorted({(b, k) for b in range(nbuf) if ring.frame_of[b] is not None for k in (0, ring.count_of[b] - 1)
-                       if ring.frame_of[b] + k >= first_timed})
+                       if ring.cams_of[b] is not None or ring.frame_number(b, k) >= first_ok})
         for b, k in held:
             imgs = ring.frame_images(b, k)
             fr = imgs[0]
+            fcam = ring.cams_of[b][k] if ring.cams_of[b] is not None else cam
             col = imgs[1].cpu().numpy().view(np.uint8).reshape(H_total, W, 4)
             dep = imgs[2].cpu().numpy()
             ys = np.flatnonzero(rows_ok)[::step]      # every step-th row of those this run rendered
             xs = np.arange(0, W, step)
             for y in ys:                               # the oracle on exactly those rows
-                ref = oracle.render(pool, W, H_total, cam, fr, args.mode, bounces=args.bounces, mirror_mask=args.mirror,
-                                    spp=args.spp, rows=(int(y), int(y) + 1), xstep=step, want_hits=False)
+                kw = dict(bounces=args.bounces, mirror_mask=args.mirror, spp=args.spp, rows=(int(y), int(y) + 1), xstep=step,
+                          want_hits=False)
+                if args.seq > 1:
+                    last = np.zeros((H_total, W, 4), dtype=np.uint8)    # fresh: the image glTexStorage2D left
+                    for f in range(fr, fr + args.seq):
+                        ref = oracle.render(pool, W, H_total, fcam, f, args.mode, last_rgba=last, **kw)
+                        last = ref["rgba"]
+                else:
+                    ref = oracle.render(pool, W, H_total, fcam, fr, args.mode, **kw)
                 bad += int((col[y, xs] != ref["rgba"][y, xs]).any(axis=1).sum())
                 bad += int((dep.view(np.uint32)[y, xs] != ref["depth"].view(np.uint32)[y, xs]).sum())
             npx += int(ys.size * xs.size)
             frames.append(int(fr))
-        verified = bad == 0 and npx > 0
-        vinfo = "frames %s as left by the timed region (%d dispatches in flight x %d frames), every %d-th pixel in x and y " \
-                "(%d pixels): rgba8 + depth bits vs the CPU oracle, %d mismatches" % (frames, nbuf, batch, step, npx, bad)
+        what = "frames %s" % frames if args.seq == 1 else "%d-frame progressive sequences starting at frame %s" % (args.seq, frames)
+        info = "%s as left by the timed region (%d dispatches in flight x %d frames%s), every %d-th pixel in x and y " \
+               "(%d pixels): rgba8 + depth bits vs the CPU oracle, %d mismatches" % (
+                   what, nbuf, batch, ", each frame with its own camera" if ring.cams_of[held[0][0]] is not None else "",
+                   step, npx, bad) if held else "nothing held"
+        return bad == 0 and npx > 0, info
+
+    verified, vinfo = None, None
+    if args.verify and rank == 0:
+        verified, vinfo = verify_ring(first_timed if args.seq == 1 else 2)
+
+    # ---- the same configuration with a camera that moves (what a drop-in user of the reference's loop gets): every frame its
+    # own camera (Camera.rotate + strafe through the host mirror) and frameNumber 1, 4 per launch, 6 launches in flight
+    moving = None
+    if (args.moving and path is None and args.seq == 1 and world == 1 and not group_mode and as_rank is None and not stub
+            and args.pipeline == 1 and not args.beam):
+        from svo_raytracer_amd.cameras import orbit_path
+        msteps = max(args.steps, 4 * batch * nbuf)
+        mpath = orbit_path(msteps + 4 * batch * nbuf, start=args.camera)
+        midx = sorted({2 * batch * nbuf + (msteps - 1) * i // 8 for i in range(9)})
+        mrays = []
+        for i in midx:
+            ctx.set_camera(mpath[0][i])
+            mrays.append(count(int(mpath[1][i]))["rays"])
+        ctx.set_camera(cam)
+        ring.start_path(*mpath)
+        run_frames(2 * batch * nbuf)
+        mel = timed(msteps)
+        ring.drain()
+        mok, minfo = verify_ring(0) if args.verify else (None, None)
+        ring.start_path(None, None)
+        moving = {"value": round(float(np.mean(mrays)) * msteps / mel / 1e6, 2), "unit": "Mrays/s", "steps": msteps,
+                  "ms_per_step": round(mel / msteps * 1e3, 4), "rays_per_frame": int(np.mean(mrays)), "verified": mok,
+                  "what": "camera path 'orbit' (Camera.rotate(0, 0.004, 0) + strafe per frame, frameNumber 1 on every frame as Main resets "
+                          "it on motion), %d frames per launch with their own cameras (svo_ring_submit_cams), %d launches in flight; %s" % (
+                              batch, nbuf, minfo)}
+        if args.verify and not mok:
+            verified = False
 
     # ---- kernel time by HIP events on the dispatch streams; then one frame at a time with the GPU to itself ----
     # (svo_ring_query: events around every submission on its slot's stream; whole batches only, so that every launch
@@ -394,7 +521,7 @@ def main(argv=None, ctx_factory=None):
     ctx.set_batch(1, 0)
     ctx.set_params(first_timed, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
     # (the median: one frame in a few hundred takes milliseconds longer on these boxes, and a mean over 20 would carry it)
-    kernel_ms_isolated = float(np.median(ctx.time_frames(2, max(5, min(args.steps, 30))))) if args.isolated else None
+    kernel_ms_isolated = float(np.median(ctx.time_frames(2, max(5, min(args.steps, 30))))) if (args.isolated and not group_mode) else None
     out_bytes_px = 8 + (16 if args.hits else 0)
     my_alg = mine[2] + mine[3] * out_bytes_px
 
@@ -408,7 +535,7 @@ def main(argv=None, ctx_factory=None):
         achieved_per_launch = my_alg * batch / (kernel_ms * 1e-3) / 1e9
         achieved = my_alg / (elapsed / args.steps) / 1e9
         key = pmc_key(args, W, H_total, nbuf, batch)
-        pmc = pmc_for(key) if world == 1 and as_rank is None else None
+        pmc = pmc_for(key) if ngpu == 1 and as_rank is None else None
         roof = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -436,32 +563,48 @@ def main(argv=None, ctx_factory=None):
                 "note": "model: instructions x class-weighted issue cycles / (1024 SIMDs x 2.4 GHz x time); ~1 = the vector issue pipe is saturated",
                 "src_hash": pmc["src_hash"], "from": "profiles/pmc_per_launch.json",
             }
-        stripes = "%d GPU(s) x interleaved tile rows (%d pixel rows each), gathered to rank 0" % (world, ring.rows_per_rank)
+        stripes = "%d GPU(s) x interleaved tile rows (%d pixel rows each), gathered to rank 0" % (ngpu, ring.rows_per_rank)
+        if group_mode:
+            stripes = "%d GPU(s) in ONE process behind the C ABI (svo_group_*), interleaved tile rows (%d pixel rows each), %s to member 0" % (
+                ngpu, ring.rows_per_rank, "RCCL send / receive" if args.exchange == "rccl" else "peer copies")
         if as_rank:
             stripes = "what-if: the stripes of rank %d of %d on one GPU, no communication" % as_rank
         # the same frame through the reference's own loop -- one dispatch, then the crosshair read-back, then the next
         # (Main.updateEarly, Main.java:132-146, 257-289): what `value` would be without frames in flight
-        one_at_a_time = (rays / (kernel_ms_isolated * 1e-3) / 1e6) if (kernel_ms_isolated and world == 1 and as_rank is None) else None
+        one_at_a_time = (rays / (kernel_ms_isolated * 1e-3) / 1e6) if (kernel_ms_isolated and ngpu == 1 and as_rank is None and path is None) else None
         line = {
             "metric": "Mrays/s (primary + 1 bounce) at 1920x1080, 8192^3 SVO",
-            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "verified": verified,
             "frames_in_flight": nbuf * batch,
             "value_one_frame_at_a_time": round(one_at_a_time, 2) if one_at_a_time else None,
+            # the default configuration with a camera that moves every frame (None where it was not measured)
+            "value_moving_camera": moving["value"] if moving else None,
+            "moving_camera": moving,
+            # N > 1: the same protocol over a longer region (a 20-step region at N = 8 is ~1.5 ms of work per rank)
+            "value_long_run": (round(rays * long_run[0] / long_run[1] / 1e6, 2) if long_run else None),
+            "long_run_steps": (long_run[0] if long_run else None),
+            "driver": ("group: one process, svo_group_*" if group_mode else "torch.distributed: one process per GPU") if ngpu > 1 else None,
             "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
             "gather_ms": ring.gather_ms(),
-            "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if world > 1 else None),
+            "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if ngpu > 1 else None),
             "config": {
-                "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %d spp, camera %s, "
-                            "frameNumber %d..%d (one per step), pipeline %d, %s" % (
+                "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %s, camera %s, "
+                            "%s, pipeline %d, %s" % (
                                 args.config or "C3", args.size, nbytes, W, H_total, args.mode,
                                 ("primary + %d bounce(s)%s" % (args.bounces - 1, ", mirror mask 0x%x" % args.mirror if args.mirror else ""))
                                 if args.mode == 0 else ("primary + shadow ray" if args.mode == 2 else "primary only"),
-                                args.spp, args.camera, first_timed, last_timed, args.pipeline, stripes),
-                "rays_per_frame": int(round(rays)), "iterations_per_ray": round(iters / max(rays, 1), 2),
+                                ("%d spp" % args.spp) if args.seq == 1 else
+                                ("%d accumulated frames per step = the reference's cross-frame accumulation (svotrace.comp:712-719) of frameNumber "
+                                 "2..%d on a fresh image, one persistent launch per step (svo_set_sequence)" % (args.seq, args.seq + 1)),
+                                args.camera if path is None else args.camera + " moving along path 'orbit' (a new camera every frame)",
+                                ("frameNumber %d..%d (one per step)" % (first_timed, last_timed)) if (args.seq == 1 and path is None) else
+                                ("frameNumber 1 on every frame (reset by the motion)" if path is not None else "every step the same sequence"),
+                                args.pipeline, stripes),
+                "rays_per_frame": int(round(rays / max(args.seq, 1))), "rays_per_step": int(round(rays)), "iterations_per_ray": round(iters / max(rays, 1), 2),
                 "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1), "nan_rays": int(round(nan_rays)),
                 "scene_build_s": round(t_build, 2), "frames_in_flight": nbuf * batch, "launches_in_flight": nbuf,
                 "frames_per_launch": batch, "use_beam": args.beam,
@@ -471,7 +614,7 @@ def main(argv=None, ctx_factory=None):
             "roofline": roof,
         }
         # ---- CPU baseline: the oracle on a bounded subsample of the same frames, 1 thread ----
-        if args.cpu_seconds > 0 and world == 1:
+        if args.cpu_seconds > 0 and ngpu == 1:
             from oracle import oracle
             okw = dict(bounces=args.bounces, mirror_mask=args.mirror, spp=args.spp, want_hits=False)
             t1 = time.perf_counter()

@@ -45,7 +45,8 @@ class _NoStream:
 
 class FrameRing:
     def __init__(self, renderer, width, height, world=1, rank=0, nbuf=3, device="cuda", dist=None,
-                 want_hits=False, force_comm=False, first_frame=2, params=None, as_rank=None, batch=1, exchange="rccl"):
+                 want_hits=False, force_comm=False, first_frame=2, params=None, as_rank=None, batch=1, exchange="rccl",
+                 advance=True):
         """params: dict(render_mode, buffer_end, use_beam, bounces, mirror_mask, spp) -- constant over the run.
         as_rank = (r, n): render what rank r of n would, without any communication (single-GPU what-if runs).
         exchange: how a rank's chunk reaches the frame owner -- "rccl": one gather per dispatch on a communication stream
@@ -70,6 +71,8 @@ class FrameRing:
         self.k = 0
         self.batch = max(1, int(batch))
         self.first_frame = int(first_frame)
+        self.advance = bool(advance)   # False: every submission starts at first_frame again (a progressive sequence per step)
+        self.path = None               # (cams [n][15], frame numbers [n]): frames with their own cameras (start_path)
         lw, lr = (self.world, self.rank) if as_rank is None else (int(as_rank[1]), int(as_rank[0]))
         self.layout_world = lw
         self.s_first, self.s_step, self.s_n, _, self.rows_per_rank = stripe_layout(self.H, lw, lr)
@@ -90,7 +93,8 @@ class FrameRing:
         self.buf = None if (self.own_images or (self.copy_mode and self.rank == 0)) else [
             torch.zeros((self.chunk_world, self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
             for _ in range(self.nbuf)]
-        self.frame_of = [None] * self.nbuf          # first frameNumber held by each slot
+        self.cams_of = [None] * self.nbuf           # per slot: the cameras of its frames when they carry their own (start_path)
+        self.frame_of = [None] * self.nbuf          # first frameNumber held by each slot (a list of them on a camera path)
         self.count_of = [0] * self.nbuf             # frames it holds
         self.scratch = (torch.zeros((self.planes, self.batch, rpr, self.W), dtype=torch.int32, device=device)
                         if self.use_comm and self.rank == 0 else None)
@@ -169,11 +173,17 @@ class FrameRing:
         plane = self.batch * self.rows_per_rank * self.W * word
         return base, base + plane, (base + 2 * plane if self.want_hits else None)
 
+    def start_path(self, cams, frame_numbers):
+        """From now on every frame carries its own camera and frameNumber (svo_ring_submit_cams): frame i of the path is
+        cams[i % len], frame_numbers[i % len].  None: back to the context's camera."""
+        self.path = None if cams is None else (cams, frame_numbers)
+        self.path_k = 0
+
     def step(self, nframes=None):
         """Submit the next `nframes` frames (default: a whole batch) as one dispatch; returns the first frameNumber."""
         n = self.batch if nframes is None else max(1, min(int(nframes), self.batch))
         b = self.dispatches % self.nbuf
-        frame = self.first_frame + self.k
+        frame = self.first_frame + (self.k if self.advance else 0)
         # a slot is re-used once its previous frames are complete (a host that reads them has waited for them anyway);
         # the other nbuf - 1 submissions keep the GPU busy meanwhile
         if self.dispatches >= self.nbuf and self.host_wait:
@@ -184,7 +194,16 @@ class FrameRing:
         self.k += n
         if self.gathered[b] is not None:
             self.streams[b].wait_event(self.gathered[b])
-        slot = self.r.ring_submit(frame, n)
+        if self.path is not None:
+            cams, fns = self.path
+            idx = [(self.path_k + i) % len(fns) for i in range(n)]
+            self.path_k += n
+            self.cams_of[b] = [cams[i] for i in idx]
+            frame = [int(fns[i]) for i in idx]
+            slot = self.r.ring_submit_cams([cams[i] for i in idx], frame)
+        else:
+            self.cams_of[b] = None
+            slot = self.r.ring_submit(frame, n)
         assert slot == b, (slot, b)
         self.last_seq[b] = self.dispatches
         self.frame_of[b] = frame
@@ -250,7 +269,7 @@ class FrameRing:
         frame order, on the frame owner (rank 0) after drain(); with as_rank only the rows that rank rendered are valid."""
         if self.own_images:                     # whole frames in the library's own images: read back through the ring
             img = self.r.ring_read(b, k, want_hits=self.want_hits)
-            out = (self.frame_of[b] + k, torch.from_numpy(img["rgba"].view("<i4").reshape(self.H, self.W)),
+            out = (self.frame_number(b, k), torch.from_numpy(img["rgba"].view("<i4").reshape(self.H, self.W)),
                    torch.from_numpy(img["depth"]))
             if self.want_hits:
                 out = out + (torch.from_numpy(img["hits"].view("<i4").reshape(self.H, self.W, 4)),)
@@ -283,8 +302,12 @@ class FrameRing:
         if self.want_hits:
             # the hit image is pixel-major (16 bytes per pixel) inside the chunk's last four plane-sized slots
             hits = order(whole[:, 2:6].reshape(cw, self.batch, self.rows_per_rank, self.W, 4)[:, k])
-            return self.frame_of[b] + k, color, depth, hits
-        return self.frame_of[b] + k, color, depth
+            return self.frame_number(b, k), color, depth, hits
+        return self.frame_number(b, k), color, depth
+
+    def frame_number(self, b, k):
+        f = self.frame_of[b]
+        return f[k] if isinstance(f, list) else f + k
 
     def rendered_rows_mask(self):
         """bool [H]: rows this rank's stripes cover (all rows on the owner after a gather)."""
@@ -309,3 +332,134 @@ def replicate_pool(dist, pool_np, rank, world, device="cuda"):
         dpool.copy_(torch.from_numpy(pool_np))
     dist.broadcast(dpool, 0)
     return dpool
+
+
+class GroupAsContext:
+    """hiplib.HipGroup behind the calls bench.py makes on a HipContext (bench.py --driver group): one process, n member
+    GPUs inside the library (include/svo_hip.h, svo_group_*).  What is per GPU fans out to the members."""
+
+    def __init__(self, group):
+        self.g = group
+        self.n = group.n
+
+    def build_from_heightmap(self, hmap, mmap):
+        return self.g.build_from_heightmap(hmap, mmap)
+
+    def pool_download(self, nbytes):
+        return self.g.pool_download(nbytes)
+
+    def resize(self, w, h):
+        self.g.resize(w, h)
+
+    def set_camera(self, cam):
+        self.g.set_camera(cam)
+
+    def set_pipeline(self, p):
+        self.g.set_pipeline(p)
+
+    def set_tuning(self, w, t):
+        self.g.set_tuning(w, t)
+
+    def set_progressive(self, on):
+        self.g.set_progressive(on)
+
+    def set_sequence(self, n, fresh=True):
+        self.g.set_sequence(n, fresh)
+
+    def set_hit_records(self, on):
+        for r in range(self.n):
+            self.g.member(r).set_hit_records(on)
+
+    def set_reserved_cus(self, n):
+        pass                                   # peer copies need no CU slots
+
+    def set_batch(self, n, stride):
+        for r in range(self.n):
+            self.g.member(r).set_batch(n, stride)
+
+    def set_params(self, *a):
+        self.g.set_params(*a)
+
+    def derived_info(self):
+        infos = [self.g.member(r).derived_info() for r in range(self.n)]   # builds every member's table
+        return infos[0]
+
+    def count_frame(self):
+        tot = None
+        for r in range(self.n):                # every member counts its own stripes; the sum is the frame's
+            c = self.g.member(r).count_frame()
+            tot = c if tot is None else {k: (tot[k] + c[k] if k not in ("max_iter", "last_dispatch_ms", "device") else max(tot[k], c[k]))
+                                         for k in c}
+        return tot
+
+    def close(self):
+        self.g.close()
+
+
+class GroupRing:
+    """FrameRing's interface over svo_group_ring_*: the exchange, the streams and the de-interleave are the library's."""
+
+    def __init__(self, group, width, height, nbuf=3, want_hits=False, first_frame=2, batch=1, exchange="copy", advance=True):
+        self.g, self.W, self.H = group, int(width), int(height)
+        self.nbuf, self.batch, self.want_hits = int(nbuf), max(1, int(batch)), want_hits
+        self.first_frame, self.advance = int(first_frame), bool(advance)
+        self.world = group.n
+        tile_rows = (self.H + TILE - 1) // TILE
+        self.rows_per_rank = ((tile_rows + self.world - 1) // self.world) * TILE
+        group.ring_create(self.nbuf, self.batch, want_hits, 1 if exchange == "rccl" else 0)
+        self.k = self.dispatches = 0
+        self.frame_of, self.count_of, self.cams_of = [None] * self.nbuf, [0] * self.nbuf, [None] * self.nbuf
+        self.timed_of = [False] * self.nbuf
+        self.timing, self.launch_ms, self.path = False, [], None
+
+    def start_path(self, cams, frame_numbers):
+        self.path = None if cams is None else (cams, frame_numbers)
+        self.path_k = 0
+
+    def step(self, nframes=None):
+        n = self.batch if nframes is None else max(1, min(int(nframes), self.batch))
+        b = self.dispatches % self.nbuf
+        frame = self.first_frame + (self.k if self.advance else 0)
+        if self.dispatches >= self.nbuf:
+            self.g.ring_wait(b)
+            if self.timing and self.timed_of[b]:
+                self.launch_ms.append((self.g.ring_query(b)["gpu_ms"], self.count_of[b]))
+        self.dispatches += 1
+        self.k += n
+        if self.path is not None:
+            cams, fns = self.path
+            idx = [(self.path_k + i) % len(fns) for i in range(n)]
+            self.path_k += n
+            self.cams_of[b] = [cams[i] for i in idx]
+            frame = [int(fns[i]) for i in idx]
+            slot = self.g.ring_submit_cams([cams[i] for i in idx], frame)
+        else:
+            self.cams_of[b] = None
+            slot = self.g.ring_submit(frame, n)
+        assert slot == b, (slot, b)
+        self.frame_of[b], self.count_of[b], self.timed_of[b] = frame, n, self.timing
+        return frame
+
+    def drain(self):
+        for b in range(min(self.nbuf, self.dispatches)):
+            self.g.ring_wait(b)
+            if self.timed_of[b]:
+                self.launch_ms.append((self.g.ring_query(b)["gpu_ms"], self.count_of[b]))
+                self.timed_of[b] = False
+
+    def gather_ms(self):
+        return None
+
+    def frame_number(self, b, k):
+        f = self.frame_of[b]
+        return f[k] if isinstance(f, list) else f + k
+
+    def frame_images(self, b, k=0):
+        img = self.g.ring_read(b, k, want_hits=self.want_hits)
+        out = (self.frame_number(b, k), torch.from_numpy(img["rgba"].view("<i4").reshape(self.H, self.W)), torch.from_numpy(img["depth"]))
+        if self.want_hits:
+            out = out + (torch.from_numpy(img["hits"].view("<i4").reshape(self.H, self.W, 4)),)
+        return out
+
+    def rendered_rows_mask(self):
+        return torch.ones(self.H, dtype=torch.bool)

@@ -106,7 +106,7 @@ def _worker(rank, world, port, argv, out_path):
 
 
 ARGS = ["--size", "64", "--width", "72", "--height", "50", "--steps", "5", "--warmup", "2", "--inflight", "2", "--batch", "2",
-        "--cpu-seconds", "0"]
+        "--cpu-seconds", "0", "--long-steps", "6"]
 
 
 @pytest.mark.parametrize("world,scaling", [(2, "strong"), (2, "weak"), (3, "strong")])
@@ -127,6 +127,18 @@ def test_bench_main_under_gloo(tmp_path, world, scaling):
     want = [oracle.render(pool, 72, h, CAMERAS["K1"], f, 0, want_hits=False)["stats"]["rays"] for f in (4, 8)]
     assert line["config"]["rays_per_frame"] == int(round(sum(want) / 2.0))
     assert line["value"] > 0 and line["unit"] == "Mrays/s" and line["scaling"] == scaling
+    # the second, longer timed region of an N > 1 run, as an extra key
+    assert line["value_long_run"] > 0 and line["long_run_steps"] == 6 and line["driver"].startswith("torch.distributed")
+
+
+def test_bench_main_camera_path_under_gloo(tmp_path):
+    """--camera-path orbit at world size 2: every frame with its own camera and frameNumber 1, verified per frame"""
+    out = str(tmp_path / "line.json")
+    argv = ARGS + ["--gpus", "2", "--camera-path", "orbit"]
+    mp.spawn(_worker, args=(2, _free_port(), argv, out), nprocs=2, join=True)
+    line = json.load(open(out))
+    assert line["verified"] is True and "its own camera" in line["config"]["verification"]
+    assert "moving along path" in line["config"]["workload"] and line["value"] > 0
 
 
 def test_bench_main_one_rank_stub(tmp_path):

@@ -51,6 +51,20 @@ class OracleStripeRenderer:
             self._one(frame + k, k * stride)
         return slot
 
+    def ring_submit_cams(self, cams, frame_numbers):
+        n = len(frame_numbers)
+        assert 1 <= n <= self.per
+        slot = self.next % len(self.slots)
+        self.next += 1
+        c, d, h, stride = self.slots[slot]
+        self.ptrs = (c, d, h)
+        keep = self.cam
+        for k in range(n):        # frame k of the submission: its own camera and frameNumber
+            self.cam = cams[k]
+            self._one(int(frame_numbers[k]), k * stride)
+        self.cam = keep
+        return slot
+
     def ring_wait(self, slot):
         pass
 
