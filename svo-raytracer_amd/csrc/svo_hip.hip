@@ -982,6 +982,12 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
 }
 
 int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
+  static const bool force_cams = getenv("SVO_FORCE_CAMS") && atoi(getenv("SVO_FORCE_CAMS")) != 0;   // A/B: the kCams kernel on a static camera
+  if (force_cams && c && nframes > 1 && nframes <= 64 && !c->use_beam && !c->progressive) {
+    FrameVar v[64];
+    for (int k = 0; k < nframes; k++) { memcpy(v[k].cam, c->cam, sizeof v[k].cam); v[k].frame_number = frame_number + k; }
+    return ring_submit(c, frame_number, nframes, v, slot, "svo_ring_submit");
+  }
   return ring_submit(c, frame_number, nframes, nullptr, slot, "svo_ring_submit");
 }
 

@@ -85,7 +85,7 @@ struct TravRegs {
   f32x2 cyz, byz;
   uint32_t octant;
   float px;
-  f32x2 pyz;
+  float py, pz;
   float t_min, t_max, sexp, h;
   int scale;
   uint32_t idx, pbase, pmask, written, iter;
@@ -102,7 +102,7 @@ __device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, 
   t.scale = kMaxScale - 1; t.sexp = 0.5f;
   if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
     t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0; t.idx = 0;
-    t.cx = t.cyz.x = t.cyz.y = t.bx = t.byz.x = t.byz.y = 0.0f; t.px = t.pyz.x = t.pyz.y = 1.0f; t.pbase = 0; t.pmask = 0;
+    t.cx = t.cyz.x = t.cyz.y = t.bx = t.byz.x = t.byz.y = 0.0f; t.px = t.py = t.pz = 1.0f; t.pbase = 0; t.pmask = 0;
     return ST_CAPPED;
   }
   if (__builtin_fabsf(d.x) < kEpsilon) d.x = kEpsilon * sign_g(d.x);
@@ -121,10 +121,10 @@ __device__ __forceinline__ int trav_init_regs(const uint64_t root, TravRegs &t, 
   t.t_min = vmax(t.t_min, 0.0f);
   t.t_min = vmax(t.t_min, t_start);   // beam pre-pass: the walk starts further along the same ray
   t.h = t.t_max;
-  t.idx = 0; t.px = 1.0f; t.pyz.x = 1.0f; t.pyz.y = 1.0f;
+  t.idx = 0; t.px = 1.0f; t.py = 1.0f; t.pz = 1.0f;
   if (1.5f * t.cx - t.bx > t.t_min) { t.idx ^= 1u; t.px = 1.5f; }
-  if (1.5f * t.cyz.x - t.byz.x > t.t_min) { t.idx ^= 2u; t.pyz.x = 1.5f; }
-  if (1.5f * t.cyz.y - t.byz.y > t.t_min) { t.idx ^= 4u; t.pyz.y = 1.5f; }
+  if (1.5f * t.cyz.x - t.byz.x > t.t_min) { t.idx ^= 2u; t.py = 1.5f; }
+  if (1.5f * t.cyz.y - t.byz.y > t.t_min) { t.idx ^= 4u; t.pz = 1.5f; }
   t.pbase = rec_cp(root);
   t.pmask = rec_mask_be(root);
   return ST_ACTIVE;
@@ -164,7 +164,7 @@ __device__ __forceinline__ Cast trav_result_regs(const BufPool &pool, const Trav
   res.raw = raw;
   res.level = (uint32_t)(kMaxScale - t.scale);
   res.normal = n;
-  float vx = t.px, vy = t.pyz.x, vz = t.pyz.y;
+  float vx = t.px, vy = t.py, vz = t.pz;
   if (t.octant & 1u) vx = 3.0f - vx - t.sexp;
   if (t.octant & 2u) vy = 3.0f - vy - t.sexp;
   if (t.octant & 4u) vz = 3.0f - vz - t.sexp;
@@ -384,7 +384,7 @@ __device__ __forceinline__ void trav_loop(const BufPool &pool, WaveStack &stk, c
       "s_branch LnoA%=\n"
       "Lend%=:\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
-      : [px] "+v"(r.px), "+{v[68:69]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v72}"(r.sexp), [h] "+v"(r.h),
+      : [px] "+v"(r.px), "+{v68}"(r.py), "+{v69}"(r.pz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v72}"(r.sexp), [h] "+v"(r.h),
         [scale] "+v"(r.scale), [idx] "+v"(r.idx), [pbase] "+v"(r.pbase), [pmask] "+v"(r.pmask), [wr] "+v"(r.written),
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [cptr] "+v"(r.cptr), [tag] "+v"(r.tag),
         "=&{v88}"(r.rlo), "=&{v89}"(r.rhi), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),

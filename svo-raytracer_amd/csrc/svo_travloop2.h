@@ -53,7 +53,7 @@ struct TravRegs2 {
   f32x2 cyz, byz;
   uint32_t octant;
   float px;
-  f32x2 pyz;
+  float py, pz;   // (two floats, not a pair: a vector member tied to v[56:57] kept px / py / pz in scratch memory around every loop)
   float t_min, t_max, sexp, h;
   int scale;
   uint32_t cs;        // child slot of the last trip (index ^ octant): the slot a stopped lane stopped on
@@ -72,7 +72,7 @@ __device__ __forceinline__ int trav_init_regs2(const uint2 rootd, TravRegs2 &t, 
   t.self = kDescRoot; t.dlo = rootd.x; t.dhi = rootd.y;
   if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
     t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0;
-    t.cx = t.cyz.x = t.cyz.y = t.bx = t.byz.x = t.byz.y = 0.0f; t.px = t.pyz.x = t.pyz.y = 1.0f;
+    t.cx = t.cyz.x = t.cyz.y = t.bx = t.byz.x = t.byz.y = 0.0f; t.px = t.py = t.pz = 1.0f;
     return ST_CAPPED;
   }
   if (__builtin_fabsf(d.x) < kEpsilon) d.x = kEpsilon * sign_g(d.x);
@@ -91,15 +91,15 @@ __device__ __forceinline__ int trav_init_regs2(const uint2 rootd, TravRegs2 &t, 
   t.t_min = vmax(t.t_min, 0.0f);
   t.t_min = vmax(t.t_min, t_start);   // beam pre-pass: the walk starts further along the same ray
   t.h = t.t_max;
-  t.px = 1.0f; t.pyz.x = 1.0f; t.pyz.y = 1.0f;
+  t.px = 1.0f; t.py = 1.0f; t.pz = 1.0f;
   if (1.5f * t.cx - t.bx > t.t_min) t.px = 1.5f;
-  if (1.5f * t.cyz.x - t.byz.x > t.t_min) t.pyz.x = 1.5f;
-  if (1.5f * t.cyz.y - t.byz.y > t.t_min) t.pyz.y = 1.5f;
+  if (1.5f * t.cyz.x - t.byz.x > t.t_min) t.py = 1.5f;
+  if (1.5f * t.cyz.y - t.byz.y > t.t_min) t.pz = 1.5f;
   return ST_ACTIVE;
 }
 
 __device__ __forceinline__ Cast trav_result_regs2(const BufPool &pool, const DescTab &tab, const TravRegs2 &t, int status) {
-  return cast_result2(pool, tab, status, t.self, t.cs, t.octant, t.iter, t.t_min, t.sexp, t.scale, t.px, t.pyz.x, t.pyz.y);
+  return cast_result2(pool, tab, status, t.self, t.cs, t.octant, t.iter, t.t_min, t.sexp, t.scale, t.px, t.py, t.pz);
 }
 
 // Run trips until at most `threshold` lanes of `act` (the lanes with status == ST_ACTIVE) are still traversing.
@@ -287,7 +287,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_mov_b32 %[st], 2\n\t"
       "s_waitcnt vmcnt(0)\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
-      : [px] "+v"(r.px), "+{v[56:57]}"(r.pyz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v58}"(r.sexp), [h] "+v"(r.h),
+      : [px] "+v"(r.px), "+{v56}"(r.py), "+{v57}"(r.pz), [tmin] "+v"(r.t_min), [tmax] "+v"(r.t_max), "+{v58}"(r.sexp), [h] "+v"(r.h),
         [scale] "+v"(r.scale), [cs] "+v"(r.cs), [self] "+v"(r.self), "+{v64}"(r.dlo), "+{v65}"(r.dhi),
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
         [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
