@@ -156,7 +156,12 @@ class FrameRing:
         t0 = time.time()
         while True:
             flags = self.r.dev_read(self.gbuf[b] + self.world * self.chunk_bytes, 4 * self.world, dtype=np.uint32)
-            if all(int(flags[r]) >= self.last_seq[b] for r in range(1, self.world)):
+            if any(int(flags[r]) > self.last_seq[b] for r in range(1, self.world)):
+                # the word carries the SENDER's submission count: a rank that submitted into this slot again before the owner
+                # read it has overwritten the frames waited for (include/svo_hip.h, svo_ring_forward_slot: LOCKSTEP)
+                raise RuntimeError("copy exchange: buffer %d holds a later submission than the owner waits for (sequence %d, "
+                                   "flags %s): ranks must submit in lockstep" % (b, self.last_seq[b], flags.tolist()))
+            if all(int(flags[r]) == self.last_seq[b] for r in range(1, self.world)):
                 return True
             if time.time() - t0 > timeout_s:
                 raise RuntimeError("copy exchange: buffer %d still waits for ranks %s (sequence %d, flags %s)" % (

@@ -1,11 +1,11 @@
 #!/bin/bash
-# interleaved A/B of bench.py argument sets (one quoted string each), ROUNDS passes, 400 steps: r04_args_ab.sh "--thresh 9" "--thresh 8" ...
+# interleaved A/B of bench.py argument sets (one quoted string each), ROUNDS passes, 400 steps: args_ab.sh "--thresh 9" "--thresh 8" ...
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_args_ab.txt; : > $O
+O=gpurun_out/args_ab.txt; : > $O
 for r in $(seq 1 ${ROUNDS:-6}); do
   for a in "$@"; do
     echo -n "[$a] " >> $O
-    timeout 600 python bench.py --steps 400 --warmup 24 --cpu-seconds 0 --isolated 0 $a 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['verified'])" >> $O 2>&1
+    timeout 600 python bench.py --steps 400 --warmup 24 --cpu-seconds 0 --isolated 0 --moving 0 $a 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['verified'])" >> $O 2>&1
   done
 done
 python - <<PY

@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0, "/root/repo")
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import numpy as np
 import svo_raytracer_amd.scene as scene

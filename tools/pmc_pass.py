@@ -6,7 +6,7 @@ one pass; PMC runs carry no trace flags; whole batches only, so that every launc
 writes gpurun_out/pmc_per_launch.json keyed like bench.py keys it, stamped with the hash of the kernel sources:
 bench.py only reports figures whose hash matches the sources it runs (copy the file to profiles/ to commit it).
 
-usage: python3 tools/pmc_pass.py [--kernel 'persist_kernel<0, svo::DescWalk>'] [--tag r04] -- <bench.py args>
+usage: python3 tools/pmc_pass.py [--kernel 'persist_kernel<0, svo::DescWalk, false>'] [--tag r04] -- <bench.py args>
 """
 import collections
 import csv
@@ -29,7 +29,7 @@ PASSES = [
 
 def main():
     argv = sys.argv[1:]
-    kernel, tag = "persist_kernel<0, svo::DescWalk>", "r04"
+    kernel, tag = "persist_kernel<0, svo::DescWalk, false>", "r04"
     while argv and argv[0] != "--":
         if argv[0] == "--kernel":
             kernel = argv[1]
@@ -51,7 +51,7 @@ def main():
         subprocess.call(["rm", "-rf", d])
         cmd = ["timeout", "-s", "KILL", "300", "rocprofv3", "--pmc"] + counters + \
               ["--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-               "--steps", str(8 * batch), "--warmup", str(batch), "--cpu-seconds", "0", "--verify", "0", "--isolated", "0"] + bench_args
+               "--steps", str(8 * batch), "--warmup", str(batch), "--cpu-seconds", "0", "--verify", "0", "--isolated", "0", "--moving", "0"] + bench_args
         with open(os.path.join(out_root, name + ".log"), "w") as lf:
             rc = subprocess.call(cmd, cwd="/tmp", env=env, stdout=lf, stderr=subprocess.STDOUT)
         print("pass %s rc %d" % (name, rc), flush=True)
