@@ -19,7 +19,10 @@ CONFIGS = [
     ("C2 2048^3 1920x1080 primary (mode 1)", 2048, 1920, 1080, 1, 2, 0, 1, "K1", 8),
     ("C3 8192^3 1920x1080 primary + 1 bounce", 8192, 1920, 1080, 0, 2, 0, 1, "K1", 16),
     ("C4 8192^3 3840x2160 4 bounces + mirror", 8192, 3840, 2160, 0, 5, 0b1000, 1, "K1", 48),
-    ("C5 8192^3 1920x1080 64 spp GI", 8192, 1920, 1080, 0, 2, 0, 64, "K1", 32),
+    # C5 in the reference's terms: the cross-frame accumulation of svotrace.comp:712-719 over frames 2..65 on a fresh image,
+    # one persistent launch (svo_set_sequence); a "frame" of the table is the whole 64-frame sequence
+    ("C5 8192^3 1920x1080 64 accumulated frames (svotrace.comp:712-719)", 8192, 1920, 1080, 0, 2, 0, -64, "K1", 32),
+    ("C5spp: 64 samples per frame, the library's reading of the dormant SAMPLES loop", 8192, 1920, 1080, 0, 2, 0, 64, "K1", 32),
 ]
 pools = {}
 ctx = hiplib.HipContext(0)
@@ -37,6 +40,10 @@ for name, n, w, h, mode, bounces, mirror, spp, camname, step in CONFIGS:
         cur = n
     pool = pools[n]
     cam = CAMERAS[camname]
+    seq = -spp if spp < 0 else 1          # negative spp in the table = frames of a progressive sequence
+    spp = 1 if spp < 0 else spp
+    ctx.set_progressive(seq > 1)
+    ctx.set_sequence(seq, True)
     ctx.resize(w, h)
     ctx.set_camera(cam)
     ctx.set_params(2, mode, 0, 0, bounces, mirror, spp)
@@ -47,11 +54,21 @@ for name, n, w, h, mode, bounces, mirror, spp, camname, step in CONFIGS:
     ms = float(np.median(ctx.time_frames(2, 8 if spp < 8 else 2)))
     # ray / byte counts: the counting pass handles one sample; spp samples differ only in the random seed
     ctx.set_params(2, mode, 0, 0, bounces, mirror, 1)
+    ctx.set_progressive(False)
+    ctx.set_sequence(1, False)
     st = ctx.count_frame()
-    rays = st["rays"] * spp
-    alg = (st["alg_bytes"]) * spp + st["pixels"] * 8
+    rays = st["rays"] * spp * seq
+    alg = (st["alg_bytes"]) * spp * seq + st["pixels"] * 8 * seq
     t0 = time.perf_counter()
-    ref = oracle.render(pool, w, h, cam, 2, mode, bounces=bounces, mirror_mask=mirror, spp=spp, xstep=step, ystep=step)
+    if seq > 1:
+        last, nrays = np.zeros((h, w, 4), dtype=np.uint8), 0
+        for f in range(2, 2 + seq):
+            ref = oracle.render(pool, w, h, cam, f, mode, bounces=bounces, mirror_mask=mirror, xstep=step, ystep=step, last_rgba=last)
+            last = ref["rgba"]
+            nrays += ref["stats"]["rays"]
+        ref["stats"]["rays"] = nrays
+    else:
+        ref = oracle.render(pool, w, h, cam, 2, mode, bounces=bounces, mirror_mask=mirror, spp=spp, xstep=step, ystep=step)
     dt = time.perf_counter() - t0
     sub = (slice(0, h, step), slice(0, w, step))
     ok = (ref["rgba"][sub] == got["rgba"][sub]).all() and \

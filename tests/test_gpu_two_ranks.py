@@ -110,3 +110,37 @@ def test_bench_two_ranks_on_one_gpu_copy_exchange():
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["verified"] is True and line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["exchange"] == "copy"
     assert line["value"] > 0
+
+
+def _bench_line(cmd, env=None, timeout=900):
+    p = subprocess.run(cmd, env=env or dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_one_rank_under_the_launcher_reproduces_the_plain_run():
+    """the driver starts N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`; at N = 1 under that launcher the line
+    must be the plain `bench.py --gpus 1` line: same workload, same ray count, verified, the value within a box's spread of a
+    20-step region (both are all start and drain)"""
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--moving", "0"]
+    plain = _bench_line([sys.executable, os.path.join(ROOT, "bench.py")] + common)
+    under = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + common)
+    for ln in (plain, under):
+        assert ln["verified"] is True and ln["n_gpus"] == 1 and ln["steps"] == 20 and ln["value_long_run"] is None
+    assert plain["config"]["rays_per_frame"] == under["config"]["rays_per_frame"]
+    assert plain["config"]["workload"] == under["config"]["workload"]
+    assert 0.8 < under["value"] / plain["value"] < 1.25, (plain["value"], under["value"])
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_group_driver_on_one_gpu(n):
+    """bench.py --gpus N --driver group: ONE process, the N members behind the C ABI (svo_group_*), here all on GPU 0;
+    the line carries the second, longer timed region of an N > 1 run"""
+    env = dict(os.environ, SVO_BENCH_ONE_GPU="1")
+    line = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--driver", "group", "--exchange", "copy",
+                        "--size", "512", "--width", "640", "--height", "360", "--steps", "12", "--warmup", "4", "--inflight", "3",
+                        "--batch", "2", "--waves", "6", "--long-steps", "24", "--cpu-seconds", "0"], env=env)
+    assert line["verified"] is True and line["n_gpus"] == n and line["driver"].startswith("group")
+    assert line["value"] > 0 and line["value_long_run"] > 0 and line["long_run_steps"] == 24
+    assert "svo_group_" in line["config"]["workload"]
