@@ -56,7 +56,7 @@ VALU_CYCLES = (41 * 2.35 + 36 * 4.3) / 77.0
 
 # frames per dispatch when --batch is not given (the same for every number of GPUs, so that the scaling curve compares like
 # with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N.
-# 6 dispatches in flight x 4 frames (tools/r04_shape*.sh, profiles/round3_experiments.txt): in a long run every shape from
+# 6 dispatches in flight x 4 frames (profiles/round3_experiments.txt): in a long run every shape from
 # 4 x 5 to 8 x 4 is within 1.5 % (5.35-5.45 Grays/s at 200 steps); a short timed region -- a driver's `--steps 20 --warmup 5`
 # -- is all start and drain, and there 6 x 4 (5.15 at 20 steps, 5.16 at 40) beats round 2's 4 x 5 (4.83, 4.99) because the
 # whole region is submitted at once and ends in ONE tail.
@@ -549,7 +549,7 @@ def main(argv=None, ctx_factory=None):
                     "kernel_ms_isolated = one frame at a time, GPU filled by one launch; traffic is per frame.  kernel_ms is taken between "
                     "HIP events around the launch on its slot's stream (svo_ring_query): with more launches in flight than fit the CUs "
                     "at once it includes the launch's wait for CU slots, which rocprofv3's kernel duration (first wave to last, "
-                    "profiles/round3_bench_default_rocprofv3.txt) does not; one launch at a time the two agree" % (batch, nbuf),
+                    "profiles/round4_bench_default_rocprofv3.txt) does not; one launch at a time the two agree" % (batch, nbuf),
         }
         if pmc:
             # the roof that binds: instruction issue.  Wave-level VALU instructions per launch x 2.5 cycles over
