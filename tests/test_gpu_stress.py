@@ -86,3 +86,95 @@ def test_random_bursts_equal_synchronous_renders(seed):
                     assert np.array_equal(depth, want["depth"].view(np.uint32)), tag
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [int(s) for s in __import__("os").environ.get("SVO_STRESS_SEEDS", "11,12,13,14,15,16").split(",")])
+def test_random_ring_submissions_with_cameras_and_sequences(seed):
+    """The round-4 submission kinds on the library's own ring, mixed at random with frames in flight: batches of a static
+    camera, batches whose frames carry their own cameras (per-slot camera tables fed from pinned staging, re-used behind
+    events), progressive sequences (slots of per-frame colours, re-used round-robin), pool edits and ring re-creation between
+    bursts.  Every frame / image must be what the same state renders synchronously, one frame at a time."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS, orbit_path
+    rng = np.random.RandomState(seed)
+    pool, _ = scene.build_scene(256)
+    ctx = hiplib.HipContext(0)
+    ref = hiplib.HipContext(0)       # the synchronous renderer: its own pool copy, table and images
+    try:
+        w, h = 208, 136
+        cur = pool.copy()
+        for c in (ctx, ref):
+            c.set_pipeline(1)
+            c.pool_upload(cur)
+            c.resize(w, h)
+        path, _ = orbit_path(64, yaw_step=0.05, pitch_step=0.01, forward=0.004)
+        frame = 2
+        for burst in range(8):
+            if rng.rand() < 0.35:
+                ptrs = rng.randint(7, cur.size - 8, size=300)
+                cur = cur.copy()
+                cur[ptrs] = rng.randint(0, 5, size=300).astype(np.uint8)
+                for c in (ctx, ref):
+                    c.pool_update(cur, int(ptrs.min()), int(ptrs.max()) + 1)
+            slots, per = int(rng.randint(1, 5)), int(rng.randint(1, 6))
+            ctx.set_tuning(int(rng.choice([0, 4, 10])), 9)
+            ctx.set_pipeline(int(rng.choice([1, 1, 1, 0, 2])))
+            ctx.ring_create(slots, per, want_hits=False)
+            plan = []
+            for d in range(slots + int(rng.randint(0, slots + 1))):      # some slots are re-used within the burst
+                kind = rng.choice(["static", "cams", "cams", "seq"])
+                mode = int(rng.choice([0, 0, 2]))
+                cam = [CAMERAS["K1"], CAMERAS["K2"]][int(rng.randint(0, 2))]
+                ctx.set_camera(cam)
+                if kind == "seq":
+                    n = int(rng.randint(2, 7))
+                    fresh = bool(rng.rand() < 0.7) or d >= slots or not plan    # a continued sequence needs a known image
+                    ctx.set_progressive(True)
+                    ctx.set_sequence(n, fresh=True)
+                    ctx.set_params(frame, mode, 0, 0, 2, 0, 1)
+                    s = ctx.ring_submit(frame, 1)
+                    plan.append((s, "seq", mode, cam, frame, n))
+                    ctx.set_progressive(False)
+                    ctx.set_sequence(1, fresh=False)
+                    frame += n
+                elif kind == "cams":
+                    n = int(rng.randint(1, per + 1))
+                    idx = rng.randint(0, 64, size=n)
+                    fns = rng.choice([1, 1, 2, 5, 77], size=n).astype(np.int32)
+                    ctx.set_params(3, mode, 0, 0, 2, 0, 1)
+                    s = ctx.ring_submit_cams(path[idx], fns)
+                    plan.append((s, "cams", mode, path[idx].copy(), fns.copy(), n))
+                else:
+                    n = int(rng.randint(1, per + 1))
+                    ctx.set_params(frame, mode, 0, 0, 2, 0, 1)
+                    s = ctx.ring_submit(frame, n)
+                    plan.append((s, "static", mode, cam, frame, n))
+                    frame += n
+            # only the LAST submission into each slot is still there
+            last = {}
+            for p in plan:
+                last[p[0]] = p
+            for s, kind, mode, cam, f0, n in last.values():
+                ctx.ring_wait(s)
+                for k in range(1 if kind == "seq" else n):
+                    got = ctx.ring_read(s, k)
+                    tag = (seed, burst, s, kind, k, n, mode)
+                    if kind == "seq":
+                        ref.set_camera(cam)
+                        ref.set_progressive(True)
+                        ref.set_sequence(1, fresh=True)
+                        for f in range(f0, f0 + n):            # one dispatch per frame, the reference's loop
+                            want = ref.render(None, None, None, None, f, mode)
+                            ref.set_sequence(1, fresh=False)
+                        ref.set_progressive(False)
+                    elif kind == "cams":
+                        want = ref.render(None, None, None, cam[k], int(f0[k]), mode)
+                    else:
+                        want = ref.render(None, None, None, cam, f0 + k, mode)
+                    assert np.array_equal(got["rgba"], want["rgba"]), tag
+                    assert np.array_equal(got["depth"].view(np.uint32), want["depth"].view(np.uint32)), tag
+            ctx.ring_destroy()
+    finally:
+        ctx.close()
+        ref.close()
