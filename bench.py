@@ -50,9 +50,9 @@ SIMDS = 1024            # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9
 # gfx950 issues wave64 VALU instructions in two classes (tools/calib_valu2.hip, profiles/round3_calib_valu2.txt; 6 waves per
 # SIMD): add / sub / mul / fma / logic / mov / right shift / v_bitop3 one per ~2.35 cycles, compares, v_cndmask, min / max,
-# bit-field, shift-and-add, count and packed-f32 ops one per ~4.3.  The traversal trip (svo_travloop2.h) is 41 of the first
-# and 36 of the second: 3.26 cycles per instruction; the round code is taken to mix alike.
-VALU_CYCLES = (41 * 2.35 + 36 * 4.3) / 77.0
+# bit-field, shift-and-add, count and packed-f32 ops one per ~4.3.  The traversal trip (svo_travloop2.h) is 42 of the first
+# and 34 of the second: 3.22 cycles per instruction; the round code is taken to mix alike.
+VALU_CYCLES = (42 * 2.35 + 34 * 4.3) / 76.0
 
 # frames per dispatch when --batch is not given (the same for every number of GPUs, so that the scaling curve compares like
 # with like): a launch needs ~1.5 M rays or more to amortise its tail, and a rank's share of a 1080p frame shrinks with N.

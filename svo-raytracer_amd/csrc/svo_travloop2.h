@@ -110,7 +110,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
                                            unsigned long long act, const int threshold, const unsigned long long cone_lanes,
                                            uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
-  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sm, sx, six, siy, siz;
+  unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sm, sx;
   int cnt;
 #ifdef SVO_STAMPS
 #define SVO_RFL(i) (uint32_t) __builtin_amdgcn_readfirstlane((int)mix[i])
@@ -132,9 +132,6 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_bfe_u32 %[t0], %[px], %[scale], 1\n\t"
       "v_bfe_u32 %[t1], v56, %[scale], 1\n\t"
       "v_bfe_u32 %[t2], v57, %[scale], 1\n\t"
-      "v_cmp_ne_u32_e64 %[six], 0, %[t0]\n\t"                     // lanes in the upper half of their parent, per axis
-      "v_cmp_ne_u32_e64 %[siy], 0, %[t1]\n\t"
-      "v_cmp_ne_u32_e64 %[siz], 0, %[t2]\n\t"
       "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"
       "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n\t"                  // idx = x | y << 1 | z << 2
       "v_xor_b32 %[cs], %[t0], %[oct]\n\t"                        // cs = idx ^ octant
@@ -167,11 +164,6 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_cmp_le_f32_e64 %[sh], v61, %[tcm]\n\t"
       // an axis that steps out of the lower half leaves the parent: POP (svotrace.comp:341; idx & step after the flip =
       // step & ~idx before it) -- on lane sets, no step mask in a register
-      "s_andn2_b64 %[sp], %[sx], %[six]\n\t"
-      "s_andn2_b64 %[sf], %[sg], %[siy]\n\t"
-      "s_or_b64 %[sp], %[sp], %[sf]\n\t"
-      "s_andn2_b64 %[sf], %[sh], %[siz]\n\t"
-      "s_or_b64 %[sp], %[sp], %[sf]\n\t"
       "s_waitcnt vmcnt(0)\n\t"
       "v_lshrrev_b32 %[bit], %[cs], v65\n\t"            // bit cs of the ne byte -> bit 0, of the has byte -> bit 8
       "v_and_b32 %[bit], %[k101], %[bit]\n\t"
@@ -182,7 +174,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = not empty & in range & !at LOD & inside & child block
       "s_and_b64 %[se], %[se], %[sa]\n\t"                 // not empty & in range & (at LOD | inside)
       "s_andn2_b64 %[sa], exec, %[se]\n\t"                // ADVANCE = the rest
-      "s_and_b64 %[sp], %[sp], %[sa]\n\t"                 // POP = the advancing lanes that leave their parent
+      "s_mov_b64 %[sp], 0\n\t"                            // (no advancing lane: no POP)
       "s_andn2_b64 %[se], %[se], %[sd]\n\t"               // HIT = not empty & in range & (at LOD | (inside & no child block))
       "s_andn2_b64 %[act], %[act], %[se]\n\t"
       // ---- DESCEND (svotrace.comp:291-327)
@@ -235,14 +227,21 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_sub_f32 v56, v56, v58\n\t"
       "s_and_b64 exec, %[sa], %[sh]\n\t"
       "v_sub_f32 v57, v57, v58\n\t"
+      "s_mov_b64 exec, %[sa]\n\t"
+      // POP detection (svotrace.comp:341) from the differing bits of the position before and after the step: a step out of the
+      // upper half clears bit `scale` of the coordinate and nothing else, a step out of the lower half borrows into the bits
+      // above -- with d = OR over the axes of (old ^ new): no step 0, step inside the parent d >> scale == 1, POP d >> scale > 1
+      // (d is what the POP section needs anyway; round 3 compared "upper half on this axis" per axis in the common part and
+      // combined lane sets with five scalar operations: same speed, eight instructions more)
+      "v_xor_b32 %[t0], %[t0], %[px]\n\t"
+      "v_bitop3_b32 %[t0], %[t0], %[t1], v56 bitop3:0xf6\n\t"   // a | (b ^ c)
+      "v_bitop3_b32 %[t0], %[t0], %[t2], v57 bitop3:0xf6\n\t"
+      "v_lshrrev_b32 %[t1], %[scale], %[t0]\n\t"
+      "v_cmp_lt_u32_e64 %[sp], 1, %[t1]\n\t"
       "s_mov_b64 exec, %[sp]\n\t"                         // left the parent: POP
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
-      // differing bits of the position before and after the step
-      "v_xor_b32 %[t0], %[t0], %[px]\n\t"
-      "v_bitop3_b32 %[t0], %[t0], %[t1], v56 bitop3:0xf6\n\t"   // a | (b ^ c)
-      "v_bitop3_b32 %[t0], %[t0], %[t2], v57 bitop3:0xf6\n\t"
       "v_or_b32 %[t0], 1, %[t0]\n\t"                      // (| 1 keeps ffbh defined)
       "v_ffbh_u32 %[t0], %[t0]\n\t"
       "v_sub_u32 %[t2], 20, %[t0]\n\t"                    // scale - 11
@@ -292,7 +291,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
         [iter] "+v"(r.iter), [lod] "+v"(r.lod_scale), [st] "+v"(status), [tcx] "=&v"(tcx), [tcm] "=&v"(tcm), [t0] "=&v"(t0),
         [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bit] "=&v"(bit), [act] "+s"(act), [sv] "=&s"(sv), [sa] "=&s"(sa),
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
-        [sp] "=&s"(sp), [sm] "=&s"(sm), [sx] "=&s"(sx), [six] "=&s"(six), [siy] "=&s"(siy), [siz] "=&s"(siz), [cnt] "=&s"(cnt)
+        [sp] "=&s"(sp), [sm] "=&s"(sm), [sx] "=&s"(sx), [cnt] "=&s"(cnt)
 #ifdef SVO_STAMPS
         , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
 #endif

@@ -129,7 +129,6 @@ def test_random_ring_submissions_with_cameras_and_sequences(seed):
                 ctx.set_camera(cam)
                 if kind == "seq":
                     n = int(rng.randint(2, 7))
-                    fresh = bool(rng.rand() < 0.7) or d >= slots or not plan    # a continued sequence needs a known image
                     ctx.set_progressive(True)
                     ctx.set_sequence(n, fresh=True)
                     ctx.set_params(frame, mode, 0, 0, 2, 0, 1)
