@@ -168,6 +168,56 @@ def test_group_pool_updates_and_builder_reach_every_member():
         one.close()
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_group_with_the_beam_pre_pass_equals_one_context(n):
+    """use_beam = 1 across the members: every member runs the coarse pass for its own stripes; the assembled frame is the
+    single context's, iteration counts included (they are what the pass changes)"""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(512)
+    w, h = 417, 243
+    one = hiplib.HipContext(0)
+    g = hiplib.HipGroup([0] * n)
+    try:
+        g.pool_upload(pool)
+        g.resize(w, h)
+        for cam in ("K0", "K1"):
+            for mode in (0, 2):
+                want = one.render(pool if (cam, mode) == ("K0", 0) else None, w, h, CAMERAS[cam], 4, mode, use_beam=1)
+                g.set_camera(CAMERAS[cam])
+                g.set_params(4, mode, 0, 1, 2, 0, 1)
+                g.ring_create(2, 2, want_hits=True)
+                s = g.ring_submit(4, 1)
+                _same(g.ring_read(s, 0, want_hits=True), want)
+    finally:
+        g.close()
+        one.close()
+
+
+def test_group_argument_errors_are_messages_not_crashes():
+    from svo_raytracer_amd import hiplib
+    g = hiplib.HipGroup([0, 0])
+    try:
+        with pytest.raises(hiplib.SvoError):
+            g.ring_create(2, 2)                       # before resize
+        g.resize(64, 48)
+        with pytest.raises(hiplib.SvoError):
+            g.ring_submit(2, 1)                       # before ring_create
+        g.ring_create(2, 2)
+        with pytest.raises(hiplib.SvoError) as e:
+            g.ring_submit(2, 1)                       # no pool on the members
+        assert "member 0" in str(e.value)
+        with pytest.raises(hiplib.SvoError):
+            g.ring_read(0, 0)                         # nothing submitted into the slot
+        with pytest.raises(hiplib.SvoError):
+            g.ring_create(9, 1)
+        with pytest.raises(hiplib.SvoError):
+            hiplib.HipGroup([99])
+    finally:
+        g.close()
+
+
 def test_group_rccl_exchange_loads_and_runs_at_one_member():
     """exchange 1 = RCCL send / receive.  One GPU cannot host two RCCL ranks, so only what can run here does: librccl is
     found, a one-member group renders; a group that repeats a device is refused by ncclCommInitAll with its message."""
