@@ -429,6 +429,10 @@ public class HipRenderer {
 
     /** Renderer.updateSSBO(bindIndex, data, start, end): a brush stroke's byte range, to every GPU. */
     public void updateSSBO(int bindIndex, ByteBuffer data, int start, int end) {
+      if (start >= end) {
+        System.out.println("Update SSBO error: Invalid parameters.");   // Renderer.java:137-140
+        return;
+      }
       check(nGroupPoolUpdate(g, MemoryUtil.memAddress0(data), start, end));
     }
 
