@@ -13,6 +13,7 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen()ed on demand, never linked
 
 struct svo_group {
   int n = 0;
@@ -30,16 +31,17 @@ struct svo_group {
   unsigned next = 0;
   // RCCL (loaded on demand: librccl is not a link-time dependency of the library)
   void *rccl = nullptr;
-  std::vector<void *> comm;                  // ncclComm_t per member
+  std::vector<ncclComm_t> comm;              // one communicator per member
   std::vector<hipStream_t> recv_stream;      // owner: one receive stream per slot
   std::vector<hipEvent_t> recv_done;
-  int (*nccl_init_all)(void **, int, const int *) = nullptr;
-  int (*nccl_destroy)(void *) = nullptr;
-  int (*nccl_send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
-  int (*nccl_recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
-  int (*nccl_group_start)() = nullptr;
-  int (*nccl_group_end)() = nullptr;
-  const char *(*nccl_error)(int) = nullptr;
+  // (declared from rccl.h's own prototypes, so that every call below is type-checked against the installed header)
+  decltype(&ncclCommInitAll) nccl_init_all = nullptr;
+  decltype(&ncclCommDestroy) nccl_destroy = nullptr;
+  decltype(&ncclSend) nccl_send = nullptr;
+  decltype(&ncclRecv) nccl_recv = nullptr;
+  decltype(&ncclGroupStart) nccl_group_start = nullptr;
+  decltype(&ncclGroupEnd) nccl_group_end = nullptr;
+  decltype(&ncclGetErrorString) nccl_error = nullptr;
   std::string err;
 };
 
@@ -94,13 +96,13 @@ static int group_load_rccl(svo_group *g) {
   void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!h) return gfail(g, SVO_E_INVALID, std::string("svo_group_ring_create: RCCL exchange asked for, but librccl cannot be loaded: ") + dlerror());
-  g->nccl_init_all = (int (*)(void **, int, const int *))dlsym(h, "ncclCommInitAll");
-  g->nccl_destroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-  g->nccl_send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclSend");
-  g->nccl_recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclRecv");
-  g->nccl_group_start = (int (*)())dlsym(h, "ncclGroupStart");
-  g->nccl_group_end = (int (*)())dlsym(h, "ncclGroupEnd");
-  g->nccl_error = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  g->nccl_init_all = (decltype(g->nccl_init_all))dlsym(h, "ncclCommInitAll");
+  g->nccl_destroy = (decltype(g->nccl_destroy))dlsym(h, "ncclCommDestroy");
+  g->nccl_send = (decltype(g->nccl_send))dlsym(h, "ncclSend");
+  g->nccl_recv = (decltype(g->nccl_recv))dlsym(h, "ncclRecv");
+  g->nccl_group_start = (decltype(g->nccl_group_start))dlsym(h, "ncclGroupStart");
+  g->nccl_group_end = (decltype(g->nccl_group_end))dlsym(h, "ncclGroupEnd");
+  g->nccl_error = (decltype(g->nccl_error))dlsym(h, "ncclGetErrorString");
   if (!g->nccl_init_all || !g->nccl_destroy || !g->nccl_send || !g->nccl_recv || !g->nccl_group_start || !g->nccl_group_end) {
     dlclose(h);
     return gfail(g, SVO_E_INVALID, "svo_group_ring_create: librccl lacks the point-to-point entry points");
@@ -108,8 +110,8 @@ static int group_load_rccl(svo_group *g) {
   g->rccl = h;
   return SVO_OK;
 }
-static int gnccl(svo_group *g, int rc, const char *what) {
-  if (rc == 0) return SVO_OK;
+static int gnccl(svo_group *g, ncclResult_t rc, const char *what) {
+  if (rc == ncclSuccess) return SVO_OK;
   return gfail(g, SVO_E_HIP, std::string(what) + ": " + (g->nccl_error ? g->nccl_error(rc) : "RCCL error"));
 }
 
@@ -153,7 +155,7 @@ int svo_group_destroy(svo_group *g) {
   if (!g) return SVO_E_INVALID;
   group_ring_free(g);
   if (g->rccl) {
-    for (void *c : g->comm) if (c) (void)g->nccl_destroy(c);
+    for (ncclComm_t c : g->comm) if (c) (void)g->nccl_destroy(c);
     // (librccl stays loaded: unloading a library that owns GPU state at exit is not worth the risk)
   }
   for (svo_ctx *c : g->m) (void)svo_destroy(c);
@@ -323,10 +325,10 @@ static int group_submit(svo_group *g, int frame_number, int nframes, const Frame
     svo_ctx *o = g->m[0];
     int rc = gnccl(g, g->nccl_group_start(), "ncclGroupStart");
     for (int r = 1; r < g->n && rc == SVO_OK; r++) {
-      rc = gnccl(g, g->nccl_recv(g->gather[(size_t)b] + (uint64_t)r * g->chunk_bytes, (size_t)g->chunk_bytes, /*ncclUint8*/ 1, r, g->comm[0],
+      rc = gnccl(g, g->nccl_recv(g->gather[(size_t)b] + (uint64_t)r * g->chunk_bytes, (size_t)g->chunk_bytes, ncclUint8, r, g->comm[0],
                                  g->recv_stream[(size_t)b]), "ncclRecv");
       if (rc == SVO_OK)
-        rc = gnccl(g, g->nccl_send(g->local[(size_t)r][(size_t)b], (size_t)g->chunk_bytes, 1, 0, g->comm[(size_t)r],
+        rc = gnccl(g, g->nccl_send(g->local[(size_t)r][(size_t)b], (size_t)g->chunk_bytes, ncclUint8, 0, g->comm[(size_t)r],
                                    g->m[(size_t)r]->ring[(size_t)b].stream), "ncclSend");
     }
     const int rc2 = gnccl(g, g->nccl_group_end(), "ncclGroupEnd");
