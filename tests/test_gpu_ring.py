@@ -306,3 +306,45 @@ def test_frames_with_their_own_cameras_in_flight(ctx, pipeline):
     ctx.set_tuning(0, 0)
     ctx.set_camera(CAMERAS["K1"])
     ctx.set_pipeline(1)
+
+
+def test_hostile_cameras_as_frames_of_one_launch_match_the_reference_shader():
+    """The fuzz fixture's cases (tests/golden/fuzz_golden.npz: NaN / infinite / denormal / 1e30 camera components, cameras on
+    faces, corners and cell boundaries, frame numbers up to +-2^31, every render mode) grouped by pool, image size and mode and
+    rendered as the frames of svo_ring_submit_cams launches -- up to eight different hostile cameras and frame numbers in ONE
+    persistent launch (the `cams` kernels) -- against the reference shader's own images."""
+    import os
+    from helpers import compare_with_golden
+    from svo_raytracer_amd import hiplib
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_golden.npz"))
+    groups = {}
+    for s in z["index"]:
+        name, pk = s.split(":")
+        w, h, frame, mode, same = (int(v) for v in z[name + "/meta"])
+        path = tuple(int(v) for v in z[name + "/path"]) if name + "/path" in z.files else (2, 0)
+        groups.setdefault((pk, w, h, mode, path), []).append((name, frame))
+    c = hiplib.HipContext(0)
+    ncases = nlaunch = 0
+    try:
+        c.set_pipeline(1)
+        for (pk, w, h, mode, (bounces, mirror)), cases in sorted(groups.items()):
+            if len(cases) < 2:
+                continue
+            c.pool_upload(z["pool/" + pk])
+            c.resize(w, h)
+            c.set_params(2, mode, 0, 0, bounces, mirror, 1)
+            c.ring_create(1, 8, want_hits=True)
+            for i in range(0, len(cases), 8):
+                part = cases[i:i + 8]
+                cams = np.stack([z[n + "/cam"] for n, _ in part]).astype(np.float32)
+                s = c.ring_submit_cams(cams, [f for _, f in part])
+                for k, (name, frame) in enumerate(part):
+                    g = dict(rgba=z[name + "/rgba"], depth_bits=z[name + "/depth_bits"], first_hit=z[name + "/first_hit"])
+                    bad = compare_with_golden(c.ring_read(s, k, want_hits=True), g)
+                    assert bad == {k2: 0 for k2 in bad}, (name, pk, mode, bad)
+                    ncases += 1
+                nlaunch += 1
+            c.ring_destroy()
+    finally:
+        c.close()
+    assert ncases >= 300 and nlaunch < ncases / 2
