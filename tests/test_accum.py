@@ -114,3 +114,42 @@ def test_hip_accumulation_with_samples_stripes_and_beam_matches_oracle(pipeline)
             last = got
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", PIPELINES)
+@pytest.mark.parametrize("seq", sequences(), ids=lambda s: s["name"])
+def test_hip_sequences_in_one_dispatch_match_the_reference_shader(seq, pipeline):
+    """svo_set_sequence: every prefix of a golden sequence as ONE dispatch (on the persistent pipeline one launch, the recurrence
+    applied in frame order afterwards) = the shader's frame at the end of that prefix -- GI converging, the shadow mode, and the
+    sequence that crosses MAX_FRAME_ITER (frames 98..101: the image freezes from frame 100 on); then the same sequence in two
+    halves, the second continuing on the image the first left (fresh = 0)."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    pool, _ = scene.build_scene(seq["n"])
+    c = hiplib.HipContext(0)
+    try:
+        c.set_pipeline(pipeline)
+        c.set_progressive(True)
+        c.pool_upload(pool)
+        c.resize(seq["w"], seq["h"])
+        c.set_camera(seq["cam"])
+        frames = seq["frames"]
+        for n in range(1, len(frames) + 1):
+            c.set_sequence(n, fresh=True)
+            c.set_params(frames[0], seq["mode"], 0, 0, 2, 0, 1)
+            c.dispatch()
+            assert (c.read_color() == seq["rgba"][n - 1]).all(), (seq["name"], n)
+            assert (c.read_depth().view(np.uint32) == seq["depth_bits"][n - 1]).all(), (seq["name"], n)
+        half = len(frames) // 2
+        if half >= 1:
+            c.set_sequence(half, fresh=True)
+            c.set_params(frames[0], seq["mode"], 0, 0, 2, 0, 1)
+            c.dispatch()
+            c.set_sequence(len(frames) - half, fresh=False)
+            c.set_params(frames[half], seq["mode"], 0, 0, 2, 0, 1)
+            c.dispatch()
+            assert (c.read_color() == seq["rgba"][-1]).all(), seq["name"]
+            assert (c.read_depth().view(np.uint32) == seq["depth_bits"][-1]).all(), seq["name"]
+    finally:
+        c.close()
