@@ -100,7 +100,12 @@ def parse(argv=None):
                          "frameNumber 1 (Main resets it on motion, Main.java:225-233, 275): svo_ring_submit_cams")
     ap.add_argument("--moving", type=int, default=1, help="also measure the default configuration with a moving camera "
                                                           "(value_moving_camera; one GPU, static runs only)")
-    ap.add_argument("--long-steps", type=int, default=400, help="N > 1: steps of the second, longer timed region (value_long_run)")
+    ap.add_argument("--long-steps", type=int, default=400, help="steps of the second, longer timed region (value_long_run; 0 = skip)")
+    ap.add_argument("--default-abi", type=int, default=1, help="also run the configuration through JNI-typed calls only, with no tuning / "
+                                                                "pipeline call (value_default_abi; one GPU, default config only)")
+    ap.add_argument("--fallback", type=int, default=1, help="N > 1 without a launcher: when a rung (driver / exchange) fails, times out or "
+                                                            "does not verify, go on with the next one in a fresh child process")
+    ap.add_argument("--rung-timeout", type=float, default=480.0, help="N > 1 without a launcher: wall-clock limit of one rung, seconds")
     ap.add_argument("--driver", choices=["torch", "group"], default="torch",
                     help="N > 1: torch = one process per GPU under torch.distributed (RCCL gather or IPC copies); group = ONE "
                          "process, the N GPUs behind the C ABI (svo_group_*: peer copies or RCCL send / receive inside the library)")
@@ -113,8 +118,9 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SVO_BENCH_BATCH", "0")),
                     help="frames per dispatch (svo_set_batch): one persistent launch carries that many consecutive frames, so "
                          "its tail is paid once per batch; 0 = default (see DEFAULT_BATCH)")
-    ap.add_argument("--waves", type=int, default=-1, help="persistent waves per CU and frame (-1 = 10 with frames in flight, else fill)")
-    ap.add_argument("--thresh", type=int, default=9, help="refill round threshold in sixteenths")
+    ap.add_argument("--waves", type=int, default=-1, help="persistent waves per CU and launch (svo_set_tuning); -1 = no call: the library's "
+                                                          "own choice (10 for a ring of several slots, fill the GPU otherwise)")
+    ap.add_argument("--thresh", type=int, default=-1, help="refill round threshold in sixteenths (svo_set_tuning); -1 = no call: the library's 9")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-oracle sample time (0 = skip)")
     ap.add_argument("--hits", type=int, default=0, help="also store 16-byte hit records per pixel")
     ap.add_argument("--verify", type=int, default=1, help="check the ring's frames against the CPU oracle after timing")
@@ -123,11 +129,15 @@ def parse(argv=None):
     ap.add_argument("--beam", type=int, default=0, help="useBeamOptimization (coarse depth pre-pass, Main.java:257-266)")
     ap.add_argument("--comm-cus", type=int, default=-1, help="CUs per XCD the render streams leave free for the collective's kernels "
                                                               "(svo_set_reserved_cus); -1 = 1 when ranks exchange tiles, else 0")
-    ap.add_argument("--exchange", choices=["rccl", "copy"], default=os.environ.get("SVO_BENCH_EXCHANGE", "rccl"),
-                    help="how a rank's tiles reach rank 0: one RCCL gather per dispatch (default), or device-to-device copies into "
-                         "rank 0's buffer through its IPC handle (svo_ring_forward_slot: SDMA, no CU slots needed)")
+    ap.add_argument("--exchange", choices=["rccl", "copy"], default=os.environ.get("SVO_BENCH_EXCHANGE") or None,
+                    help="how a rank's tiles reach rank 0: one RCCL gather per dispatch (default of --driver torch), or device-to-device "
+                         "copies into rank 0's buffer (svo_ring_forward_slot: SDMA, no CU slots needed; default of --driver group, "
+                         "whose RCCL exchange has never run between two devices)")
     ap.add_argument("--as-rank", default=None, help="r/n: render what rank r of n would, on one GPU, no communication")
     args = ap.parse_args(argv)
+    args.exchange_given = args.exchange is not None
+    if args.exchange is None:
+        args.exchange = "copy" if args.driver == "group" else "rccl"
     preset = PRESETS[args.config or "C3"]
     for k, v in preset.items():
         if getattr(args, k) is None:
@@ -166,16 +176,107 @@ def _free_port():
     return p
 
 
-def launch_ranks(args):
-    """--gpus N > 1 without a launcher: start the N ranks as a child torch.distributed.run.  Nothing in this
-    process has touched the GPU yet (device_count() does not initialise it)."""
-    import torch
-    have = torch.cuda.device_count()
-    if args.gpus > have:
-        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd)
+def _strip_opts(argv, names):
+    """argv without the options in `names` (each takes one value; `--opt v` and `--opt=v` forms)"""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in names:
+            skip = True
+            continue
+        if any(a.startswith(n + "=") for n in names):
+            continue
+        out.append(a)
+    return out
+
+
+def ladder(args):
+    """The rungs `--gpus N` tries in order: the driver / exchange asked for (default: one process per GPU under
+    torch.distributed with an RCCL gather), then the paths that need less of the node -- the same driver with device-to-device
+    copies instead of the collective (no CU slots next to the persistent waves), then ONE process with the N GPUs behind
+    the C ABI (svo_group_*, peer copies)."""
+    first = (args.driver, args.exchange)
+    if not args.fallback:
+        return [first]
+    order = [("torch", "rccl"), ("torch", "copy"), ("group", "copy")]
+    # what comes after the rung asked for; never back to something that needs more of the node than what failed
+    return [first] + (order[order.index(first) + 1:] if first in order else [("group", "copy")])
+
+
+def rung_command(args, driver, exchange, argv):
+    rest = _strip_opts(argv, ("--driver", "--exchange"))
+    me = os.path.abspath(__file__)
+    if driver == "torch":
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), me] + rest + ["--driver", "torch", "--exchange", exchange]
+    return [sys.executable, me] + rest + ["--driver", "group", "--exchange", exchange]
+
+
+def run_rung(cmd, timeout_s, env=None):
+    """One rung = one FRESH child process (group), never a retry inside a process that has initialised HIP.  Returns
+    (rc or None on timeout, the last JSON line of its stdout or None, the last line of its stderr)."""
+    import signal
+    import tempfile
+    with tempfile.TemporaryFile("w+") as out, tempfile.TemporaryFile("w+") as err:
+        p = subprocess.Popen(cmd, stdout=out, stderr=err, env=env, start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            rc = None
+            for sig in (signal.SIGTERM, signal.SIGKILL):     # the process group this rung started, nothing else
+                try:
+                    os.killpg(p.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    p.wait(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+        out.seek(0)
+        err.seek(0)
+        line = None
+        for ln in out.read().splitlines():
+            ln = ln.strip()
+            if ln.startswith("{") and ln.endswith("}"):
+                try:
+                    line = json.loads(ln)
+                except Exception:
+                    pass
+        etxt = [ln for ln in err.read().splitlines() if ln.strip()]
+        return rc, line, (etxt[-1][-300:] if etxt else "")
+
+
+def launch_ranks(args, argv=None, runner=run_rung):
+    """--gpus N > 1 without a launcher.  This process never touches the GPU (device_count() does not initialise it): it
+    walks the ladder, one fresh child per rung with a wall-clock limit, and prints the line of the first rung that exits
+    zero with a verified frame -- carrying `driver`, `exchange` and `fallback_from` (the rungs that failed before it, each
+    with how it failed)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if runner is run_rung:
+        import torch
+        have = torch.cuda.device_count()
+        if args.gpus > have and os.environ.get("SVO_BENCH_ONE_GPU", "0") != "1":   # (tests: every rank / member on GPU 0)
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have))
+    failed = []
+    env = dict(os.environ, SVO_BENCH_CHILD="1")
+    for driver, exchange in ladder(args):
+        cmd = rung_command(args, driver, exchange, argv)
+        rc, line, last_err = runner(cmd, args.rung_timeout, env)
+        ok = rc == 0 and line is not None and line.get("verified") is not False
+        if ok:
+            line["fallback_from"] = failed
+            print(json.dumps(line), flush=True)
+            return 0
+        how = "timed out after %d s" % int(args.rung_timeout) if rc is None else \
+            ("exit code %d" % rc if (rc != 0 or line is None) else "verified: false")
+        failed.append({"driver": driver, "exchange": exchange, "failed": how, "stderr_tail": last_err})
+        print("bench.py: rung driver=%s exchange=%s failed (%s): %s" % (driver, exchange, how, last_err), file=sys.stderr, flush=True)
+    print(json.dumps({"metric": "Mrays/s (primary + 1 bounce) at 1920x1080, 8192^3 SVO", "value": None, "n_gpus": args.gpus,
+                      "error": "every rung failed", "fallback_from": failed}), flush=True)
+    return 1
 
 
 KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop2.h", "svo_trav2.h", "svo_derive.hip.h", "svo_travloop.h", "svo_trav.h",
@@ -233,6 +334,130 @@ def pmc_for(key):
     return e
 
 
+def run_default_abi(pool, W, H, cam, args, nbuf, batch, rays_per_frame, first_timed):
+    """The configuration of the headline as a drop-in host drives it: a context of its own, JNI-typed calls only (the natives
+    of integration/java/src/engine/HipRenderer.java, include/svo_hip_jni.h), and NO tuning / pipeline / hit-record call -- the
+    launch shape is whatever the library picks for a ring of `nbuf` slots.  Same frame numbers, warm-up and step count as the
+    timed region of `value`; then the same again over --long-steps; the last frame is checked against the CPU oracle."""
+    import ctypes
+    import numpy as np
+    from svo_raytracer_amd import hiplib
+    L = hiplib.lib()
+    vp, jint, jlong, jfloat = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+    def fn(name, res, *a):
+        f = getattr(L, "Java_src_engine_HipRenderer_" + name)
+        f.restype = res
+        f.argtypes = [vp, vp] + list(a)
+        return lambda *v: f(None, None, *v)
+
+    nCreate, nDestroy = fn("nCreate", jlong, jint), fn("nDestroy", jint, jlong)
+    nPoolUpload = fn("nPoolUpload", jint, jlong, jlong, jlong)
+    nSetCamera = fn("nSetCamera", jint, jlong, *([jfloat] * 15))
+    nSetParams = fn("nSetParams", jint, jlong, *([jint] * 7))
+    nResize = fn("nResize", jint, jlong, jint, jint)
+    nRingCreate = fn("nRingCreate", jint, jlong, jint, jint, jint)
+    nRingSubmit = fn("nRingSubmit", jint, jlong, jint, jint)
+    nRingWait = fn("nRingWait", jint, jlong, jint)
+    nRingReadColor = fn("nRingReadColor", jint, jlong, jint, jint, jlong)
+    nRingReadDepth = fn("nRingReadDepth", jint, jlong, jint, jint, jlong)
+    nDerivedInfo = fn("nDerivedInfo", jlong, jlong, jlong)
+    nLaunchInfo = fn("nLaunchInfo", jint, jlong, jlong)
+
+    def ok(rc, what):
+        if rc < 0:
+            raise RuntimeError("%s returned %d" % (what, rc))
+        return rc
+
+    j = nCreate(0)
+    if j == 0:
+        raise RuntimeError("nCreate returned 0")
+    try:
+        ok(nPoolUpload(j, pool.ctypes.data, pool.size), "nPoolUpload")
+        ok(nSetCamera(j, *[float(v) for v in np.asarray(cam, np.float32).reshape(-1)]), "nSetCamera")
+        ok(nResize(j, W, H), "nResize")
+        ok(nRingCreate(j, nbuf, batch, 0), "nRingCreate")
+        ok(nDerivedInfo(j, 0), "nDerivedInfo")     # the table resident before the timed region, as for `value`
+        ok(nSetParams(j, 2, args.mode, int(pool.size), 0, args.bounces, args.mirror, 1), "nSetParams")
+        state = {"frame": 2, "used": [False] * nbuf, "next": 0, "last": None}
+
+        def run(n):
+            while n > 0:
+                k = min(batch, n)
+                b = state["next"]
+                if state["used"][b]:
+                    ok(nRingWait(j, b), "nRingWait")    # awaitFrames(slot) before the slot's images are rendered over
+                slot = ok(nRingSubmit(j, state["frame"], k), "nRingSubmit")
+                state["used"][slot] = True
+                state["last"] = (slot, k, state["frame"])
+                state["next"] = (slot + 1) % nbuf
+                state["frame"] += k
+                n -= k
+
+        def drain():
+            for b in range(nbuf):
+                if state["used"][b]:
+                    ok(nRingWait(j, b), "nRingWait")
+
+        def timed(n):
+            drain()
+            t0 = time.perf_counter()
+            run(n)
+            drain()
+            return time.perf_counter() - t0
+
+        run(nbuf * batch)      # the new context's pool copy and table touched once, as the counting passes do for `value`'s context
+        run(args.warmup)
+        el = timed(args.steps)
+        wpc = ctypes.c_int32(0)
+        waves = nLaunchInfo(j, ctypes.addressof(wpc))
+        out = {"value": round(rays_per_frame * args.steps / el / 1e6, 2), "unit": "Mrays/s", "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(el / args.steps * 1e3, 4),
+               "launch_shape": {"persistent_waves": int(waves), "waves_per_cu": int(wpc.value), "slots": nbuf, "frames_per_slot": batch},
+               "what": "a second context driven through the JNI-typed exports only (nCreate, nPoolUpload, nSetCamera, nResize, "
+                       "nRingCreate(%d, %d, 0), nSetParams, nRingSubmit / nRingWait): no nSetTuning, nSetPipeline or nSetHitRecords "
+                       "call -- the library's defaults" % (nbuf, batch)}
+        if args.long_steps > 0:
+            el2 = timed(args.long_steps)
+            out["value_long_run"] = round(rays_per_frame * args.long_steps / el2 / 1e6, 2)
+            out["long_run_steps"] = args.long_steps
+        if args.verify:
+            from oracle import oracle   # the checker; after the timed regions
+            slot, k, first = state["last"]
+            fr = first + k - 1
+            rgba = np.zeros((H, W, 4), np.uint8)
+            depth = np.zeros((H, W), np.float32)
+            ok(nRingReadColor(j, slot, k - 1, rgba.ctypes.data), "nRingReadColor")
+            ok(nRingReadDepth(j, slot, k - 1, depth.ctypes.data), "nRingReadDepth")
+            step = 32
+            bad, npx = 0, 0
+            xs = np.arange(0, W, step)
+            for y in range(0, H, step):
+                ref = oracle.render(pool, W, H, cam, fr, args.mode, bounces=args.bounces, mirror_mask=args.mirror, spp=1,
+                                    rows=(y, y + 1), xstep=step, want_hits=False)
+                bad += int((rgba[y, xs] != ref["rgba"][y, xs]).any(axis=1).sum())
+                bad += int((depth.view(np.uint32)[y, xs] != ref["depth"].view(np.uint32)[y, xs]).sum())
+                npx += int(xs.size)
+            out["verified"] = bad == 0 and npx > 0
+            out["verification"] = "frame %d of the long run, every %d-th pixel in x and y (%d pixels) vs the CPU oracle: %d mismatches" % (fr, step, npx, bad)
+        return out
+    finally:
+        nDestroy(j)
+
+
+def stamps_for(key):
+    """Mean lanes traversing per trip of the assembly loop (tools/stamps.py on an -DSVO_STAMPS=1 build of the same sources:
+    profiles/stamps_per_launch.json) -- only if taken on the current kernel sources."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "stamps_per_launch.json")))
+    except Exception:
+        return None
+    e = j.get(key) or j.get("default")
+    if not e or e.get("src_hash") != source_hash():
+        return None
+    return {k: v for k, v in e.items() if k != "src_hash"}
+
+
 def main(argv=None, ctx_factory=None):
     """ctx_factory: tests only -- a callable(local_rank) returning a CPU stand-in for hiplib.HipContext; the whole of main()
     then runs on CPU tensors under gloo (tests/test_bench_main_gloo.py), exercising the sharding, counting, timing
@@ -241,8 +466,8 @@ def main(argv=None, ctx_factory=None):
     stub = ctx_factory is not None
     dev = "cpu" if stub else "cuda"
     group_mode = args.driver == "group" and "RANK" not in os.environ
-    if args.gpus > 1 and "RANK" not in os.environ and not group_mode:
-        sys.exit(launch_ranks(args))
+    if args.gpus > 1 and "RANK" not in os.environ and os.environ.get("SVO_BENCH_CHILD") != "1" and not stub:
+        sys.exit(launch_ranks(args, argv))
     # the dispatches in flight, the gather and torch's own stream each want a hardware queue of their own; HIP's default
     # of 4 makes two of the frame streams share one (their launches then serialise).  Read when the runtime starts.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -323,10 +548,11 @@ def main(argv=None, ctx_factory=None):
     batch = args.batch if args.batch > 0 else default_batch(args, ngpu if as_rank is None else as_rank[1])
     if args.seq > 1:
         batch = 1      # a step is a whole sequence: one submission, one image
-    waves = args.waves if args.waves >= 0 else (10 if nbuf > 1 else 0)
-    if args.pipeline == 1:
-        ctx.set_tuning(waves, args.thresh)  # several frames in flight share the CUs: 10 persistent waves per CU and
-                                            # frame, rounds once 7/16 of the traversing lanes have stopped (tools/history/sweep*.sh)
+    # The launch shape is the library's own (include/svo_hip.h, svo_set_tuning: a ring of several slots runs 10 persistent
+    # waves per CU and launch, rounds once 7/16 of the traversing lanes have stopped; one launch at a time fills the GPU):
+    # what a drop-in host gets without any call is what is measured here.  --waves / --thresh are experiment knobs.
+    if args.pipeline == 1 and (args.waves >= 0 or args.thresh >= 0):
+        ctx.set_tuning(max(args.waves, 0), max(args.thresh, 0))
     ctx.set_hit_records(bool(args.hits))
     if args.pipeline == 1 and hasattr(ctx, "derived_info"):
         ctx.derived_info()   # the interior-descriptor table is part of what is resident in HBM before the timed region starts
@@ -423,10 +649,10 @@ def main(argv=None, ctx_factory=None):
         dist.all_gather(tall, torch.tensor([elapsed], dtype=torch.float64, device=dev))
         rank_ms = [float(t.item()) / args.steps * 1e3 for t in tall]
         elapsed = max(float(t.item()) for t in tall)
-    # N > 1: a driver's 20-step region is 1.5 ms of work per rank at N = 8 -- all start and drain, and millisecond stalls of a
-    # box do not average out.  The same protocol again over a longer region, as an extra key.
+    # A driver's 20-step region is 11 ms at N = 1 and 1.5 ms of work per rank at N = 8 -- all start and drain, and millisecond
+    # stalls of a box do not average out.  The same protocol again over a longer region, as an extra key.
     long_run = None
-    if (world > 1 or (group_mode and ngpu > 1)) and args.long_steps > 0 and args.seq == 1:
+    if args.long_steps > 0 and args.seq == 1 and as_rank is None:
         ring.drain()
         el = timed(args.long_steps)
         if world > 1:
@@ -488,36 +714,59 @@ def main(argv=None, ctx_factory=None):
     moving = None
     if (args.moving and path is None and args.seq == 1 and world == 1 and not group_mode and as_rank is None and not stub
             and args.pipeline == 1 and not args.beam):
-        from svo_raytracer_amd.cameras import orbit_path
-        msteps = max(args.steps, 4 * batch * nbuf)
-        mpath = orbit_path(msteps + 4 * batch * nbuf, start=args.camera)
-        midx = sorted({2 * batch * nbuf + (msteps - 1) * i // 8 for i in range(9)})
-        mrays = []
-        for i in midx:
-            ctx.set_camera(mpath[0][i])
-            mrays.append(count(int(mpath[1][i]))["rays"])
-        ctx.set_camera(cam)
-        ring.start_path(*mpath)
-        run_frames(2 * batch * nbuf)
-        mel = timed(msteps)
-        ring.drain()
-        mok, minfo = verify_ring(0) if args.verify else (None, None)
-        ring.start_path(None, None)
-        moving = {"value": round(float(np.mean(mrays)) * msteps / mel / 1e6, 2), "unit": "Mrays/s", "steps": msteps,
-                  "ms_per_step": round(mel / msteps * 1e3, 4), "rays_per_frame": int(np.mean(mrays)), "verified": mok,
-                  "what": "camera path 'orbit' (Camera.rotate(0, 0.004, 0) + strafe per frame, frameNumber 1 on every frame as Main resets "
-                          "it on motion), %d frames per launch with their own cameras (svo_ring_submit_cams), %d launches in flight; %s" % (
-                              batch, nbuf, minfo)}
-        if args.verify and not mok:
-            verified = False
+        # (a leg behind the headline: whatever goes wrong here -- the host mirror missing, a build problem -- is reported on
+        # the line, it must not lose the region already measured; a pixel mismatch still fails `verified`)
+        try:
+            from svo_raytracer_amd.cameras import orbit_path
+            msteps = max(args.steps, 4 * batch * nbuf)
+            mpath = orbit_path(msteps + 4 * batch * nbuf, start=args.camera)
+            midx = sorted({2 * batch * nbuf + (msteps - 1) * i // 8 for i in range(9)})
+            mrays = []
+            for i in midx:
+                ctx.set_camera(mpath[0][i])
+                mrays.append(count(int(mpath[1][i]))["rays"])
+            ctx.set_camera(cam)
+            ring.start_path(*mpath)
+            run_frames(2 * batch * nbuf)
+            mel = timed(msteps)
+            ring.drain()
+            mok, minfo = verify_ring(0) if args.verify else (None, None)
+            ring.start_path(None, None)
+            moving = {"value": round(float(np.mean(mrays)) * msteps / mel / 1e6, 2), "unit": "Mrays/s", "steps": msteps,
+                      "ms_per_step": round(mel / msteps * 1e3, 4), "rays_per_frame": int(np.mean(mrays)), "verified": mok,
+                      "what": "camera path 'orbit' (Camera.rotate(0, 0.004, 0) + strafe per frame, frameNumber 1 on every frame as Main resets "
+                              "it on motion), %d frames per launch with their own cameras (svo_ring_submit_cams), %d launches in flight; %s" % (
+                                  batch, nbuf, minfo)}
+            if args.verify and not mok:
+                verified = False
+        except Exception as e:     # noqa: BLE001
+            moving = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                ctx.set_camera(cam)
+                ring.start_path(None, None)
+                ring.drain()
+            except Exception:
+                pass
+
+    # ---- the same configuration as a drop-in host drives it: JNI-typed calls only (what HipRenderer.java's natives are), a
+    # context of its own, NO tuning / pipeline / hit-record call -- createFrameRing(6, 4), submitFrames, awaitFrames
+    default_abi = None
+    if (args.default_abi and path is None and args.seq == 1 and ngpu == 1 and as_rank is None and not stub and not group_mode
+            and args.pipeline == 1 and not args.beam and args.spp == 1 and rank == 0):
+        try:
+            default_abi = run_default_abi(pool, W, H_total, cam, args, nbuf, batch, rays, first_timed)
+            if args.verify and default_abi.get("verified") is False:
+                verified = False
+        except Exception as e:     # noqa: BLE001
+            default_abi = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- kernel time by HIP events on the dispatch streams; then one frame at a time with the GPU to itself ----
     # (svo_ring_query: events around every submission on its slot's stream; whole batches only, so that every launch
     # averaged carries the same number of frames)
     full = [m for m, n in ring.launch_ms if m > 0 and n == batch] or [m for m, n in ring.launch_ms if m > 0]
     kernel_ms = float(np.mean(full)) if full else 0.0   # with nbuf launches in flight
-    if args.pipeline == 1:
-        ctx.set_tuning(0, args.thresh)   # one frame at a time: fill the GPU
+    if args.pipeline == 1 and args.waves > 0:
+        ctx.set_tuning(0, max(args.thresh, 0))   # one frame at a time: back to the library's choice (fill the GPU)
     ctx.set_batch(1, 0)
     ctx.set_params(first_timed, args.mode, nbytes, args.beam, args.bounces, args.mirror, args.spp)
     # (the median: one frame in a few hundred takes milliseconds longer on these boxes, and a mean over 20 would carry it)
@@ -529,10 +778,8 @@ def main(argv=None, ctx_factory=None):
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays * args.steps / elapsed / 1e6
-        # `nbuf` launches share the GPU at any time, each for `kernel_ms`; the device-level rate the HBM
-        # roofline is about is bytes per launch / (timed region / launches).  With one frame in flight the two
-        # are the same number.
-        achieved_per_launch = my_alg * batch / (kernel_ms * 1e-3) / 1e9
+        # `nbuf` launches share the GPU at any time; the device-level rate the HBM roofline is about is bytes per frame /
+        # time per frame.  With one frame in flight that is bytes per launch / kernel time.
         achieved = my_alg / (elapsed / args.steps) / 1e9
         key = pmc_key(args, W, H_total, nbuf, batch)
         pmc = pmc_for(key) if ngpu == 1 and as_rank is None else None
@@ -540,29 +787,46 @@ def main(argv=None, ctx_factory=None):
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": (int((pmc["fetch_size_kb"] * 1024 * 2 + pmc["write_size_kb"] * 1024) / batch) if pmc else None),
+            "traffic_note": "per frame: (FETCH_SIZE x 2 + WRITE_SIZE) KB of separate rocprofv3 --pmc passes; the x 2 is the scattered-load "
+                            "correction of profiles/r01_fetch_size_calibration.txt (gfx950 tallies a 128-byte request as 64)",
             "kernel_ms": round(kernel_ms, 4), "launches_in_flight": nbuf, "frames_per_launch": batch,
-            "achieved_per_launch": round(achieved_per_launch, 2),
             "kernel_ms_isolated": round(kernel_ms_isolated, 4) if kernel_ms_isolated is not None else None,
             "alg_bytes_per_launch": int(my_alg * batch),
             "note": "a launch carries %d frame(s) and %d launches overlap, so kernel_ms > ms_per_step (= one frame); achieved = "
-                    "bytes per frame / ms_per_step (device level), achieved_per_launch = bytes per launch / kernel_ms; "
-                    "kernel_ms_isolated = one frame at a time, GPU filled by one launch; traffic is per frame.  kernel_ms is taken between "
-                    "HIP events around the launch on its slot's stream (svo_ring_query): with more launches in flight than fit the CUs "
-                    "at once it includes the launch's wait for CU slots, which rocprofv3's kernel duration (first wave to last, "
-                    "profiles/round4_bench_default_rocprofv3.txt) does not; one launch at a time the two agree" % (batch, nbuf),
+                    "bytes per frame / ms_per_step (device level); kernel_ms_isolated = one frame at a time, GPU filled by one launch.  "
+                    "kernel_ms is taken between HIP events around the launch on its slot's stream (svo_ring_query): with more launches "
+                    "in flight than fit the CUs at once it includes the launch's wait for CU slots, which rocprofv3's kernel duration "
+                    "(first wave to last, profiles/) does not; one launch at a time the two agree" % (batch, nbuf),
         }
         if pmc:
-            # the roof that binds: instruction issue.  Wave-level VALU instructions per launch x 2.5 cycles over
-            # what 1024 SIMDs offer in one step; lane utilisation = thread-cycles / (64 x active VALU cycles)
-            roof["binding_roof"] = {
+            # the roof that binds: vector instruction issue.  Counters first (per launch of the PMC passes, hash-gated), the
+            # class-weighted issue model next to them.
+            o = pmc.get("other", {})
+            br = {
                 "kind": "valu-issue",
                 "valu_insts_per_frame": int(pmc["sq_insts_valu"] / batch),
-                "valu_issue_frac": round(pmc["sq_insts_valu"] / batch * VALU_CYCLES / (SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4),
                 "valu_lane_util": round(pmc["sq_thread_cycles_valu"] / (64.0 * pmc["sq_active_inst_valu"]), 4),
-                "cycles_per_valu_inst": round(VALU_CYCLES, 3),
-                "note": "model: instructions x class-weighted issue cycles / (1024 SIMDs x 2.4 GHz x time); ~1 = the vector issue pipe is saturated",
                 "src_hash": pmc["src_hash"], "from": "profiles/pmc_per_launch.json",
             }
+            if o.get("GRBM_GUI_ACTIVE") and o.get("SQ_WAVE_CYCLES"):
+                # SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD's VALU is busy: x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
+                br["valu_busy_frac_counters"] = round(pmc["sq_active_inst_valu"] * 4.0 / (o["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS), 4)
+                br["wait_inst_any_per_wave_cycle"] = round(o.get("SQ_WAIT_INST_ANY", 0.0) / o["SQ_WAVE_CYCLES"], 4)
+                br["waves_per_simd_in_pmc_pass"] = round(o["SQ_WAVE_CYCLES"] * 4.0 / (o["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS), 3)
+                br["counters_note"] = ("valu_busy_frac_counters = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), the SQ counters read "
+                                       "as quad-cycles, measured with the PMC passes' own occupancy; wait_inst_any_per_wave_cycle = "
+                                       "SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; waves_per_simd_in_pmc_pass = SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE / 8 x 1024): counter "
+                                       "passes serialise launches, so they run at a lower occupancy than the timed region's 6 waves per SIMD")
+            br["model"] = {
+                "valu_issue_frac": round(pmc["sq_insts_valu"] / batch * VALU_CYCLES / (SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4),
+                "cycles_per_valu_inst": round(VALU_CYCLES, 3),
+                "note": "a MODEL with a fitted constant, not a counter: instructions x class-weighted issue cycles (calibrated on isolated "
+                        "instruction kinds, tools/calib_valu2.hip) / (1024 SIMDs x 2.4 GHz x time); ~1 = the vector issue pipe is saturated",
+            }
+            st = stamps_for(key)
+            if st:
+                br["lanes_traversing_per_trip"] = st
+            roof["binding_roof"] = br
         stripes = "%d GPU(s) x interleaved tile rows (%d pixel rows each), gathered to rank 0" % (ngpu, ring.rows_per_rank)
         if group_mode:
             stripes = "%d GPU(s) in ONE process behind the C ABI (svo_group_*), interleaved tile rows (%d pixel rows each), %s to member 0" % (
@@ -583,14 +847,17 @@ def main(argv=None, ctx_factory=None):
             # the default configuration with a camera that moves every frame (None where it was not measured)
             "value_moving_camera": moving["value"] if moving else None,
             "moving_camera": moving,
-            # N > 1: the same protocol over a longer region (a 20-step region at N = 8 is ~1.5 ms of work per rank)
+            # the same configuration through JNI-typed calls only, no tuning / pipeline call: what a drop-in host gets by default
+            "value_default_abi": default_abi["value"] if default_abi else None,
+            "default_abi": default_abi,
+            # the same protocol over a longer region (a 20-step region is 11 ms at N = 1, ~1.5 ms of work per rank at N = 8)
             "value_long_run": (round(rays * long_run[0] / long_run[1] / 1e6, 2) if long_run else None),
             "long_run_steps": (long_run[0] if long_run else None),
             "driver": ("group: one process, svo_group_*" if group_mode else "torch.distributed: one process per GPU") if ngpu > 1 else None,
             "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
             "gather_ms": ring.gather_ms(),
-            "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if ngpu > 1 else None),
+            "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if ngpu > 1 else None), "fallback_from": [],
             "config": {
                 "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %s, camera %s, "
                             "%s, pipeline %d, %s" % (

@@ -153,10 +153,16 @@ int svo_set_stripes(svo_ctx *ctx, int first_tile_row, int tile_row_step, int n_t
  * refill and in-place bounce regeneration; 2 = stage-per-kernel wavefront tracing with
  * compacted ray queues.  All three produce identical bytes; a new context runs pipeline 1 (the fast one). */
 int svo_set_pipeline(svo_ctx *ctx, int pipeline);
-/* pipeline-1 launch shape: persistent waves per CU (0 = fill the GPU: right for one frame at a time;
- * about 10 when the caller keeps 2-3 frames in flight on alternating streams) and the refill round
- * threshold in sixteenths (0 = default 9: a round starts once 7/16 of the traversing lanes have stopped) */
+/* pipeline-1 launch shape: persistent waves per CU and the refill round threshold in sixteenths (0 = default 9: a round
+ * starts once 7/16 of the traversing lanes have stopped).  waves_per_cu = 0 (what a new context has) = automatic: a
+ * dispatch on the context's stream fills the GPU (right for one frame at a time); the submissions of a ring with more than
+ * one slot (svo_ring_create / svo_group_ring_create) take 10 waves per CU and launch, so that the next launch's waves find
+ * CU slots while the previous launch drains -- the shape bench.py's headline is measured on, without any call.  A
+ * positive value is used as given everywhere (a caller that alternates its own streams with svo_set_stream: about 10). */
 int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_sixteenths);
+/* shape of the last pipeline-1 launch of the context: persistent waves launched, waves per CU they were sized by, round
+ * threshold in sixteenths (any pointer may be NULL).  Diagnostic: what svo_set_tuning's automatic choice resolved to. */
+int svo_launch_info(svo_ctx *ctx, int *waves, int *waves_per_cu, int *round_threshold_sixteenths);
 /* the reference's dormant cross-frame accumulation (commented out at svotrace.comp:712-719; MAX_FRAME_ITER :43):
  * when enabled and frameNumber > 1, a pixel's colour becomes (frameNumber * last + colour) / (frameNumber + 1), `last`
  * being what the colour image holds from the previous dispatch (rgba8, as imageLoad returns it), and stays `last` from
@@ -173,7 +179,11 @@ int svo_set_progressive(svo_ctx *ctx, int enabled);
  * applies the reference's recurrence in frame order, quantising to rgba8 between frames as imageStore / imageLoad do: the
  * same bytes as one dispatch per frame, without their tails.  Sequences that do not fit 4 GB of slots, more than one
  * sample per pixel, and the other pipelines fall back to one launch per frame.  nframes = 1 (default): one frame per
- * dispatch.  A sequence is one frame of a batch: svo_set_batch must be 1. */
+ * dispatch.  A sequence is one frame of a batch: svo_set_batch must be 1.
+ * On a ring of MORE than one slot (svo_ring_* / svo_group_ring_*) every submission lands in another image, so a progressive
+ * submission must start fresh (fresh != 0): with fresh = 0 -- or plain svo_set_progressive(1) without a sequence -- "the
+ * image the previous dispatch left" would be the frame of `slots` submissions ago, and the submission is refused
+ * (SVO_E_INVALID).  Continue an accumulation with svo_dispatch, or on a ring of one slot. */
 int svo_set_sequence(svo_ctx *ctx, int nframes, int fresh);
 /* Throughput mode: every dispatch renders `nframes` consecutive frames of the current camera -- frameNumber,
  * frameNumber + 1, ... exactly what nframes turns of Main.updateEarly with a static camera render (Main.java:275 only
@@ -206,10 +216,13 @@ int svo_set_hit_records(svo_ctx *ctx, int enabled);
 
 /* ---- dispatch ------------------------------------------------------------------- */
 /* replaces Renderer.useProgram + dispatchCompute(traceShader, W/8, H/8, 1):
- * glDispatchCompute + glMemoryBarrier (Renderer.java:114-121, Main.java:267,285).
- * Returns when the frame is complete. */
+ * glDispatchCompute + glMemoryBarrier (Renderer.java:114-121, Main.java:267,285) -- and waits for the frame
+ * (last_dispatch_ms of svo_stats is its GPU time). */
 int svo_dispatch(svo_ctx *ctx);
-/* same, but only enqueues on the context's stream */
+/* the same with GL's own semantics: both GL calls return at once and the reference's wait is the next frame's glGetTexImage
+ * (Main.java:132-146), so its quad draw / ImGui / input overlap the trace.  Only enqueues on the context's stream; every
+ * svo_read_* waits for that stream first, every pool mutator for the whole device.  What Renderer.dispatchCompute of the
+ * host mirrors (HipRenderer.java, host/svo_host.hpp) calls. */
 int svo_dispatch_async(svo_ctx *ctx);
 int svo_sync(svo_ctx *ctx);
 /* run the frame once more with counters on and fill svo_stats (untimed diagnostic pass) */
@@ -330,7 +343,12 @@ int svo_group_set_progressive(svo_group *g, int enabled);
 int svo_group_set_sequence(svo_group *g, int nframes, int fresh);
 /* the size of the whole frame; every member renders its stripes of it */
 int svo_group_resize(svo_group *g, int width, int height);
-/* as svo_ring_*: `slots` submissions in flight of up to frames_per_slot frames each, on every member at once */
+/* as svo_ring_*: `slots` submissions in flight of up to frames_per_slot frames each, on every member at once.
+ * exchange 0 (recommended): every member's slot forwards its chunk to the owner with a peer copy on its own stream behind the
+ * launch (SDMA over xGMI; no CU slots needed).  exchange 1 (EXPERIMENTAL: has only ever run with one member -- no
+ * multi-GPU node was available to the build): one RCCL send / receive pair per member inside ncclGroupStart / End; the
+ * members' slot streams are then created with at least one CU per XCD left free for RCCL's kernels (svo_set_reserved_cus),
+ * because persistent waves hold their CU slots for a whole launch. */
 int svo_group_ring_create(svo_group *g, int slots, int frames_per_slot, int want_hits, int exchange);
 int svo_group_ring_destroy(svo_group *g);
 int svo_group_ring_submit(svo_group *g, int frame_number, int nframes, int *slot);

@@ -75,6 +75,9 @@ jint Java_src_engine_HipRenderer_nSync(void *env, void *cls, jlong ctx);
 jint Java_src_engine_HipRenderer_nSetStream(void *env, void *cls, jlong ctx, jlong hip_stream);
 jint Java_src_engine_HipRenderer_nSetPipeline(void *env, void *cls, jlong ctx, jint pipeline);
 jint Java_src_engine_HipRenderer_nSetTuning(void *env, void *cls, jlong ctx, jint waves_per_cu, jint round_threshold_sixteenths);
+/* svo_launch_info: persistent waves of the last pipeline-1 launch (what the automatic launch shape resolved to); waves per
+ * CU through the address (0 = not wanted) */
+jint Java_src_engine_HipRenderer_nLaunchInfo(void *env, void *cls, jlong ctx, jlong waves_per_cu_addr);
 jint Java_src_engine_HipRenderer_nSetDerived(void *env, void *cls, jlong ctx, jint mode);
 jint Java_src_engine_HipRenderer_nSetHitRecords(void *env, void *cls, jlong ctx, jint enabled);
 jint Java_src_engine_HipRenderer_nSetRows(void *env, void *cls, jlong ctx, jint y0, jint y1);

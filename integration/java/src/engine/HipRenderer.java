@@ -82,17 +82,33 @@ public class HipRenderer {
   public void useProgram(Shader shader) {
   }
 
-  /** glDispatchCompute + glMemoryBarrier: returns when the frame is complete. */
+  /**
+   * glDispatchCompute + glMemoryBarrier (Renderer.java:118-121): both GL calls return at once, and so does this -- the frame
+   * is enqueued (svo_dispatch_async).  The wait is where the reference has it: the next read-back (readDepthPixel /
+   * readFramebuffer / readDepth / readHits = next frame's glGetTexImage, Main.java:132-146) waits for the frame, as do
+   * addSSBO / updateSSBO / getSSBO; the quad draw, ImGui and input of Main's loop overlap the trace as they do under GL.
+   */
   public void dispatchCompute(Shader shader, int numGroupsX, int numGroupsY, int numGroupsZ) {
+    if (prepareDispatch(shader, numGroupsX, numGroupsY))
+      check(nDispatchAsync(ctx));
+  }
+
+  /** The same, but returns when the frame is complete (svo_dispatch); the stats' last_dispatch_ms is then its GPU time. */
+  public void dispatchComputeAndWait(Shader shader, int numGroupsX, int numGroupsY, int numGroupsZ) {
+    if (prepareDispatch(shader, numGroupsX, numGroupsY))
+      check(nDispatch(ctx));
+  }
+
+  private boolean prepareDispatch(Shader shader, int numGroupsX, int numGroupsY) {
     if (shader == null || shader.computeProgram != 1)
-      return;
+      return false;
     if (width == 0) {
       width = numGroupsX * Constants.COMPUTE_GROUP_SIZE;
       height = numGroupsY * Constants.COMPUTE_GROUP_SIZE;
     }
     check(nResize(ctx, width, height));
     check(nSetParams(ctx, frameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
-    check(nDispatch(ctx));
+    return true;
   }
 
   public void addSSBO(int bindIndex, ByteBuffer data) {
@@ -199,7 +215,11 @@ public class HipRenderer {
   // several viewports) can keep `slots` launches of `framesPerSlot` consecutive frames in flight instead: the
   // library owns the streams and the device images.
 
-  /** Create (or re-create) the ring; call after the first dispatchCompute / setImageSize has fixed the image size. */
+  /**
+   * Create (or re-create) the ring; call after the first dispatchCompute / setImageSize has fixed the image size.  With more
+   * than one slot the submissions run in the launch shape bench.py's headline is measured on (10 persistent waves per CU and
+   * launch, rounds at 9/16) by themselves -- no setTuning call needed; setTuning with a positive wave count overrides it.
+   */
   public void createFrameRing(int slots, int framesPerSlot, boolean wantHits) {
     check(nResize(ctx, width, height));
     check(nRingCreate(ctx, slots, framesPerSlot, wantHits ? 1 : 0));
@@ -283,7 +303,8 @@ public class HipRenderer {
     return d;
   }
 
-  /** Launch shape of the persistent pipeline: about 10 waves per CU with several launches in flight, 0 = fill the GPU. */
+  /** Launch shape of the persistent pipeline: 0 waves (default) = automatic -- fill the GPU for dispatchCompute, 10 per CU for
+   *  the submissions of a ring with more than one slot; a positive count is used as given. */
   public void setTuning(int wavesPerCu, int roundThresholdSixteenths) {
     check(nSetTuning(ctx, wavesPerCu, roundThresholdSixteenths));
   }
@@ -356,6 +377,16 @@ public class HipRenderer {
 
   public void setHitRecords(boolean on) {
     check(nSetHitRecords(ctx, on ? 1 : 0));
+  }
+
+  /** Persistent waves of the last launch (what the automatic launch shape resolved to); wavesPerCu[0] = waves per CU. */
+  public int lastLaunchWaves(int[] wavesPerCu) {
+    ByteBuffer w = MemoryUtil.memAlloc(4);
+    int n = nLaunchInfo(ctx, MemoryUtil.memAddress(w));
+    if (wavesPerCu != null && wavesPerCu.length > 0)
+      wavesPerCu[0] = w.getInt(0);
+    MemoryUtil.memFree(w);
+    return n;
   }
 
   /** 0 = walk the pool's records as the shader does, 1 (default) = the interior-descriptor table when the pool allows */
@@ -569,6 +600,7 @@ public class HipRenderer {
   private static native int nSetStream(long ctx, long hipStream);
   private static native int nSetPipeline(long ctx, int pipeline);
   private static native int nSetTuning(long ctx, int wavesPerCu, int roundThresholdSixteenths);
+  private static native int nLaunchInfo(long ctx, long wavesPerCuAddr);
   private static native int nSetDerived(long ctx, int mode);
   private static native int nSetHitRecords(long ctx, int enabled);
   private static native int nSetRows(long ctx, int y0, int y1);

@@ -13,7 +13,26 @@
 #pragma once
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen()ed on demand, never linked
+// RCCL: types and prototypes only -- the library is dlopen()ed on demand, never linked.  From the installed header when
+// there is one (every call below is then type-checked against it); a ROCm install without RCCL's headers still builds the
+// library (the single-GPU path and the peer-copy exchange need none of this) from the declarations below, which state
+// the seven point-to-point entry points as RCCL's public API documents them.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 struct svo_group {
   int n = 0;
@@ -266,6 +285,10 @@ int svo_group_ring_create(svo_group *g, int slots, int frames_per_slot, int want
   }
   for (int r = 0; r < g->n; r++) {
     svo_ctx *c = g->m[(size_t)r];
+    // RCCL's send / receive kernels need CU slots next to persistent waves that hold theirs for a whole launch: with the
+    // RCCL exchange every member's slot streams leave at least one CU per XCD free (what the torch driver does for its
+    // gather, bench.py --comm-cus); the peer-copy exchange runs on the SDMA engines and needs none
+    if (exchange == 1 && g->n > 1 && c->reserved_cus < 1) c->reserved_cus = 1;
     int rc = gmember(g, r, ring_create_impl(c, slots, frames_per_slot, want_hits, false));
     if (rc) return rc;
     for (int b = 0; b < slots; b++) {

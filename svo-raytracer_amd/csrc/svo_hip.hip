@@ -490,6 +490,14 @@ int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_sixteenths)
   return SVO_OK;
 }
 
+int svo_launch_info(svo_ctx *c, int *waves, int *waves_per_cu, int *round_threshold_sixteenths) {
+  if (!c) return SVO_E_INVALID;
+  if (waves) *waves = c->pb.last_blocks;
+  if (waves_per_cu) *waves_per_cu = c->pb.last_per_cu;
+  if (round_threshold_sixteenths) *round_threshold_sixteenths = c->pb.thresh_num;
+  return SVO_OK;
+}
+
 static int ensure_derived(svo_ctx *c);
 
 int svo_set_derived(svo_ctx *c, int mode) {
@@ -915,6 +923,12 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
   if (!c) return SVO_E_INVALID;
   if (c->ring.empty()) return fail(c, SVO_E_INVALID, std::string(who) + ": svo_ring_create first");
   if (nframes < 1 || nframes > c->ring_frames) return fail(c, SVO_E_INVALID, std::string(who) + ": 1..frames_per_slot frames");
+  // the cross-frame accumulation blends with what the previous dispatch left in the SAME image (svotrace.comp:712-719); a
+  // ring of several slots hands every submission another image, so a continued accumulation would blend with the frame of
+  // `slots` submissions ago.  Sequences that start on a fresh image (svo_set_sequence(n, 1)) are whole in one slot.
+  if (c->progressive && !c->seq_fresh && c->ring.size() > 1)
+    return fail(c, SVO_E_INVALID, std::string(who) + ": a progressive accumulation that continues on the previous image needs a ring of "
+                                  "ONE slot (or svo_dispatch); with several slots start every submission fresh: svo_set_sequence(n, 1)");
   HIPCHK(c, hipSetDevice(c->device));
   const int si = (int)(c->ring_next % (unsigned)c->ring.size());
   svo_ctx::RingSlot &s = c->ring[(size_t)si];
@@ -954,7 +968,10 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
     c->frame_number = cams[0].frame_number;
   }
   if (e == hipSuccess) e = hipEventRecord(s.e0, s.stream);
+  // the launch shape a ring of several slots gets unless svo_set_tuning named one: kRingWavesPerCu persistent waves per CU
+  c->pb.in_ring = c->ring.size() > 1;
   if (e == hipSuccess) rc = launch_frame(c, false);
+  c->pb.in_ring = false;
   if (e == hipSuccess && rc == SVO_OK) e = hipEventRecord(s.e1, s.stream);
   if (e == hipSuccess && rc == SVO_OK && s.fwd_dst) {
     // the slot's frames travel to the frame owner behind the launch, on the same stream: a device-to-device copy (SDMA
@@ -1223,12 +1240,13 @@ int svo_output_device_ptrs(svo_ctx *c, void **color, void **depth, void **hits) 
 extern "C" {
 
 #ifdef SVO_STAMPS
-// diagnostic builds only: raw copy of the persistent pipeline's counter ring (8 sets x 256 B)
+// diagnostic builds only: the diagnostics words of the persistent pipeline's last counter set (16 x u64, then the
+// 64-word histogram of lanes traversing per trip): 384 bytes
 int svo_debug_heads(svo_ctx *c, void *out) {
   if (!c || !out || !c->pb.heads) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemcpy(out, c->pb.heads + (size_t)((c->pb.frames - 1) % kHeadSets) * kHeadWords + 8 * kHeadStride, 128, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out, c->pb.heads + (size_t)((c->pb.frames - 1) % kHeadSets) * kHeadWords + 8 * kHeadStride, 384, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
 #endif

@@ -90,6 +90,11 @@ jint Java_src_engine_HipRenderer_nSetPipeline(void *, void *, jlong ctx, jint pi
 jint Java_src_engine_HipRenderer_nSetTuning(void *, void *, jlong ctx, jint waves_per_cu, jint thresh) {
   return svo_set_tuning(CTX(ctx), waves_per_cu, thresh);
 }
+jint Java_src_engine_HipRenderer_nLaunchInfo(void *, void *, jlong ctx, jlong waves_per_cu_addr) {
+  int waves = 0;
+  const int rc = svo_launch_info(CTX(ctx), &waves, (int *)(intptr_t)waves_per_cu_addr, nullptr);
+  return rc == SVO_OK ? (jint)waves : (jint)rc;
+}
 jint Java_src_engine_HipRenderer_nSetDerived(void *, void *, jlong ctx, jint mode) { return svo_set_derived(CTX(ctx), mode); }
 jint Java_src_engine_HipRenderer_nSetHitRecords(void *, void *, jlong ctx, jint enabled) { return svo_set_hit_records(CTX(ctx), enabled); }
 jint Java_src_engine_HipRenderer_nSetRows(void *, void *, jlong ctx, jint y0, jint y1) { return svo_set_rows(CTX(ctx), y0, y1); }

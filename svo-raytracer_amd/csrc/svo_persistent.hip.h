@@ -34,7 +34,11 @@ namespace svo {
 // stamps (SVO_STAMPS build) showed the load wait growing from 420 to 2000 cycles per iteration as rounds
 // became more frequent; with separate lines it stays below 500.
 constexpr int kHeadStride = 32;
+#ifdef SVO_STAMPS
+constexpr int kHeadWords = 8 * kHeadStride + 32 + 64;  // + diagnostics words + the histogram of lanes traversing per trip
+#else
 constexpr int kHeadWords = 8 * kHeadStride + 32;  // + diagnostics words
+#endif
 
 struct PersistArgs {
   const uint8_t *pool;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
   unsigned long long st_round = 0, st_trav = 0, st_nround = 0, st_ntrip = 0, st_shade = 0, st_load = 0, st_t0 = __builtin_readcyclecounter();
   const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device
   unsigned long long st_dry = 0;
-  uint32_t st_mix[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // trips / lanes, by section (trav_loop)
+  uint32_t st_mix[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // trips / lanes, by section (trav_loop); [8]: per-lane histogram word (trav_loop2)
 #endif
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
@@ -546,6 +550,10 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
     for (int i = 0; i < 8; i += 2)   // dbg[12..15]: lanes << 32 | trips, for the whole trip / descend / advance / pop
       atomicAdd(dbg + 12 + i / 2, ((unsigned long long)st_mix[i + 1] << 32) + st_mix[i]);
 
+  }
+  atomicAdd(a.heads + 8 * kHeadStride + 32 + lane, st_mix[8]);
+  if (lane == 0u) {
+    unsigned long long *dbg = (unsigned long long *)(a.heads + 8 * kHeadStride);
     atomicAdd(dbg + 0, st_round); atomicAdd(dbg + 1, st_trav); atomicAdd(dbg + 2, st_nround); atomicAdd(dbg + 3, st_ntrip); atomicAdd(dbg + 4, st_shade); atomicAdd(dbg + 5, st_load);
   }
 #endif
@@ -554,6 +562,10 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
 // a.fold > 1: tiles per group of a band's walk.  1 / 8 / 64 / 512 / all: 4.47 / 4.49 / 4.47 / 4.41 / 4.20 Grays/s at 64
 // samples per pixel (tools/history/r03_fold2.sh): a group's samples should be in flight together, not a whole band's
 constexpr int kFoldGroup = 8;
+// Persistent waves per CU and launch when several launches share the GPU (a ring of more than one slot): the next launch's
+// waves take the CUs the previous launch's tail frees.  Swept in rounds 2-4 (profiles/round4_experiments.txt: 10 waves with
+// rounds at 9/16 is the shape every headline number was measured on; 16: -6 %).
+constexpr int kRingWavesPerCu = 10;
 constexpr int kHeadSets = 8;   // counter sets: one per frame in flight (its sample launches follow one another on one
                                // stream and share it), reused round-robin
 constexpr int kFaccSets = 4;   // colour-sum buffers (spp > 1): one per frame, reused round-robin
@@ -571,7 +583,10 @@ struct PersistBuffers {
   size_t facc_floats = 0;   // floats in each colour-sum buffer
   int blocks = 0;
   int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/history/sweep8.sh)
-  int waves_per_cu = 0;      // 0 = as many as fit (occupancy query)
+  int waves_per_cu = 0;      // 0 = automatic: as many as fit (occupancy query) for one launch at a time, kRingWavesPerCu for
+                             // the submissions of a ring with more than one slot (in_ring, set around the launch by ring_submit)
+  bool in_ring = false;
+  int last_blocks = 0, last_per_cu = 0;   // shape of the last launch (svo_launch_info)
   int max_per_cu = 16, max_per_cu_desc = 16, cus = 256;   // resident waves per CU: byte walk / descriptor walk
   int cus_reserved = 0;   // CUs the launching stream may not use (svo_set_reserved_cus): fewer persistent waves
   unsigned launches = 0, frames = 0;
@@ -676,8 +691,10 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     if (const char *e2 = getenv("SVO_PERSIST_THRESH")) b.thresh_num = atoi(e2);
   }
   {
-    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (desc ? b.max_per_cu_desc : b.max_per_cu);
+    const int fill = desc ? b.max_per_cu_desc : b.max_per_cu;
+    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (b.in_ring ? std::min(kRingWavesPerCu, fill) : fill);
     b.blocks = (b.cus - b.cus_reserved) * per_cu;
+    b.last_per_cu = per_cu;
   }
   const int spp = f.spp < 1 ? 1 : f.spp;
   const bool resolve = spp > 1 || f.progressive;   // colours go through the float planes and the resolve kernel
@@ -735,6 +752,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   }
   const long long work = (long long)f.ntiles * (f.batch > 1 ? f.batch : 1) * fold;
   const int blocks = work < (long long)b.blocks ? (int)work : b.blocks;
+  b.last_blocks = blocks;
   // a ring of counter sets: frames may be in flight on different streams at the same time.  A frame's sample launches
   // are ordered by its stream, so they share the frame's set; only another frame's re-use waits (for the event)
   const int hset = (int)(frame_no % kHeadSets);

@@ -47,6 +47,16 @@ namespace svo {
   "buffer_load_dwordx2 v[64:65], %[self], %[rsd], 0 offen\n\t"
 #endif
 
+#ifdef SVO_STAMPS
+#define SVO_HIST                                        \
+  "s_mov_b64 exec, -1\n\t"                             \
+  "v_cmp_eq_u32 vcc, %[cnt], %[lane]\n\t"              \
+  "v_addc_co_u32 %[hist], vcc, 0, %[hist], vcc\n\t"    \
+  "s_mov_b64 exec, %[act]\n\t"
+#else
+#define SVO_HIST
+#endif
+
 // per-ray constants and state in the register layout of trav_loop2()
 struct TravRegs2 {
   float cx, bx;
@@ -116,6 +126,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
 #define SVO_RFL(i) (uint32_t) __builtin_amdgcn_readfirstlane((int)mix[i])
   uint32_t c0 = SVO_RFL(0), c1 = SVO_RFL(1), c2 = SVO_RFL(2), c3 = SVO_RFL(3), c4 = SVO_RFL(4), c5 = SVO_RFL(5), c6 = SVO_RFL(6), c7 = SVO_RFL(7);
 #undef SVO_RFL
+  uint32_t hist = mix[8];   // lane L: trips of this wave that ran with exactly L lanes traversing
 #else
   (void)mix;
 #endif
@@ -128,6 +139,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "Ltrip%=:\n\t"
       "s_mov_b64 exec, %[act]\n\t"
       SVO_COUNT("c0", "c1", "exec")
+      SVO_HIST
       // ---- child slot (bit `scale` of the three position components), iteration cap (svotrace.comp:263-266)
       "v_bfe_u32 %[t0], %[px], %[scale], 1\n\t"
       "v_bfe_u32 %[t1], v56, %[scale], 1\n\t"
@@ -293,15 +305,18 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
         [sp] "=&s"(sp), [sm] "=&s"(sm), [sx] "=&s"(sx), [cnt] "=&s"(cnt)
 #ifdef SVO_STAMPS
-        , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7)
+        , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7), [hist] "+v"(hist)
 #endif
       : [cx] "v"(r.cx), [bx] "v"(r.bx),
         [cy] "v"(r.cyz.x), [cz] "v"(r.cyz.y), [by] "v"(r.byz.x), [bz] "v"(r.byz.y), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
         [lds8] "v"(lds8), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
+#ifdef SVO_STAMPS
+        , [lane] "v"(lane)
+#endif
       : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
   r.iter += kMaxIter + 1u;
 #ifdef SVO_STAMPS
-  mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7;
+  mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7; mix[8] = hist;
 #endif
 }
 

@@ -22,7 +22,7 @@ EXPORTS = [
     "svo_ring_read_depth", "svo_ring_read_hits", "svo_ring_read_pixel", "svo_ring_bind_slot", "svo_ring_device_ptrs",
     "svo_set_reserved_cus", "svo_pool_commit", "svo_ring_forward_slot", "svo_dev_alloc", "svo_dev_free", "svo_dev_read",
     "svo_ipc_export", "svo_ipc_open", "svo_ipc_close", "svo_set_sequence", "svo_ring_submit_cams",
-    "svo_build_from_heightmap16",
+    "svo_build_from_heightmap16", "svo_launch_info",
     "svo_group_create", "svo_group_destroy", "svo_group_last_error", "svo_group_size", "svo_group_member", "svo_group_pool_upload",
     "svo_group_pool_update", "svo_group_pool_download", "svo_group_build_from_heightmap", "svo_group_set_camera",
     "svo_group_set_params", "svo_group_set_pipeline", "svo_group_set_tuning", "svo_group_set_progressive", "svo_group_set_sequence",
@@ -407,6 +407,12 @@ class HipContext:
 
     def set_tuning(self, waves_per_cu=0, round_threshold_sixteenths=0):
         self._chk(self._L.svo_set_tuning(self._h, int(waves_per_cu), int(round_threshold_sixteenths)))
+
+    def launch_info(self):
+        """shape of the last pipeline-1 launch: what the automatic launch shape (svo_set_tuning's 0) resolved to"""
+        w, p, t = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._chk(self._L.svo_launch_info(self._h, ctypes.byref(w), ctypes.byref(p), ctypes.byref(t)))
+        return {"waves": w.value, "waves_per_cu": p.value, "round_threshold_sixteenths": t.value}
 
     def set_derived(self, mode):
         """0 = walk the pool's records as the shader does, 1 (default) = walk the interior-descriptor table when the

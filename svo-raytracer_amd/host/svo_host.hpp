@@ -272,15 +272,18 @@ class Renderer {
     }
   }
   void useProgram(Shader *s) { current = s; }          // :114-116
-  // glDispatchCompute(gx, gy, gz) + glMemoryBarrier: the image is gx*8 x gy*8 unless setImageSize was called
+  // glDispatchCompute(gx, gy, gz) + glMemoryBarrier: the image is gx*8 x gy*8 unless setImageSize was called.  Both GL calls
+  // return at once (Renderer.java:118-121) and so does this: the frame is enqueued (svo_dispatch_async); the wait is where the
+  // reference has it -- the next read-back (readFramebuffer / readDepth / readHits / readDepthPixel = next frame's
+  // glGetTexImage, Main.java:132-146) -- and in every SSBO call.
   void dispatchCompute(Shader *s, int numGroupsX, int numGroupsY, int numGroupsZ) {   // :118-121
     (void)numGroupsZ;
-    if (!ensure() || !s || s->computeProgram != 1) return;
-    if (width == 0) { width = numGroupsX * Constants::COMPUTE_GROUP_SIZE; height = numGroupsY * Constants::COMPUTE_GROUP_SIZE; }
-    check(svo_resize(ctx, width, height));
-    check(svo_set_camera(ctx, cam, cam + 3, cam + 6, cam + 9, cam + 12));
-    check(svo_set_params(ctx, frameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
-    check(svo_dispatch(ctx));
+    if (prepareDispatch(s, numGroupsX, numGroupsY)) check(svo_dispatch_async(ctx));
+  }
+  // the same, returning when the frame is complete (svo_dispatch; svo_get_stats().last_dispatch_ms = its GPU time)
+  void dispatchComputeAndWait(Shader *s, int numGroupsX, int numGroupsY, int numGroupsZ) {
+    (void)numGroupsZ;
+    if (prepareDispatch(s, numGroupsX, numGroupsY)) check(svo_dispatch(ctx));
   }
   void setImageSize(int w, int h) { width = w; height = h; }   // glTexStorage2D in Main.java:69,76
   void addSSBO(int bindIndex, const uint8_t *data, size_t nbytes) {   // :123-129
@@ -305,6 +308,8 @@ class Renderer {
   void readFramebuffer(void *rgba8) { if (ensure()) check(svo_read_color(ctx, rgba8)); }
   void readDepth(float *d) { if (ensure()) check(svo_read_depth(ctx, d)); }
   void readHits(svo_hit *h) { if (ensure()) check(svo_read_hits(ctx, h)); }
+  // the crosshair pick of Main.updateEarly (Main.java:132-146) without the full-frame read-back; waits for the frame in flight
+  float readDepthPixel(int x, int y) { float d = 0.0f; if (ensure()) check(svo_read_pixel(ctx, x, y, nullptr, &d, nullptr)); return d; }
   // dormant shader features (svotrace.comp:444, 500-504, 668-670); defaults = the live behaviour
   void setPathOptions(int bounces_, uint32_t mirrorMask_, int spp_) { bounces = bounces_; mirrorMask = mirrorMask_; spp = spp_; }
   svo_ctx *context() { ensure(); return ctx; }
@@ -313,6 +318,14 @@ class Renderer {
 
  private:
   Renderer() { shaders.reserve(16); }
+  bool prepareDispatch(Shader *s, int numGroupsX, int numGroupsY) {
+    if (!ensure() || !s || s->computeProgram != 1) return false;
+    if (width == 0) { width = numGroupsX * Constants::COMPUTE_GROUP_SIZE; height = numGroupsY * Constants::COMPUTE_GROUP_SIZE; }
+    check(svo_resize(ctx, width, height));
+    check(svo_set_camera(ctx, cam, cam + 3, cam + 6, cam + 9, cam + 12));
+    check(svo_set_params(ctx, frameNumber, renderMode, bufferEnd, useBeam, bounces, mirrorMask, spp));
+    return true;
+  }
   bool ensure() {
     if (ctx) return true;
     if (svo_create(0, &ctx) != SVO_OK) { lastErr = "svo_create failed (no MI355X visible)"; ctx = nullptr; return false; }

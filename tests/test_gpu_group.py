@@ -247,3 +247,116 @@ def test_group_rccl_exchange_loads_and_runs_at_one_member():
         assert "nccl" in str(e.value).lower() or "rccl" in str(e.value).lower()
     finally:
         g2.close()
+
+
+# ---- BASELINE configs 4 and 5 -- the two that say "across 8 x MI355X" -- THROUGH the 8-way split, against the reference
+# shader's own images.  Eight members on the one device of the box: stripes, chunk layout, forward copies and
+# the de-interleave are exactly what eight devices run; only the copies are device-local.
+@pytest.fixture(scope="module")
+def pool8192():
+    import zlib
+    import svo_raytracer_amd.scene as scene
+    from test_config3 import GOLD
+    z = np.load(GOLD)
+    pool, _ = scene.build_scene(8192)
+    assert pool.size == int(z["pool_size"][0]) and zlib.crc32(pool.tobytes()) == int(z["pool_crc32"][0])
+    return pool
+
+
+@pytest.fixture(scope="module")
+def group8(pool8192):
+    from svo_raytracer_amd import hiplib
+    g = hiplib.HipGroup([0] * 8)
+    g.pool_upload(pool8192)        # one upload, seven device-to-device copies
+    yield g
+    g.close()
+
+
+def test_config4_through_the_8_way_split_equals_the_reference_shader(group8):
+    """config 4: 8192^3, 3840 x 2160, 5 path segments, the shader's own mirror test (svotrace.comp:444, 500-504), tile rows
+    split over 8 members, read back de-interleaved -- colour, depth bits, hit pointer / value / normal / level / iter of every
+    8th pixel as the reference shader renders them (tests/golden/config3_8192.npz: c4_f2)"""
+    from test_config3 import GOLD, _check, _meta
+    z = np.load(GOLD)
+    step = int(z["step"][0])
+    w, h, frame, mode, bounces, mirror = _meta(z, "c4_f2")
+    assert (w, h, bounces) == (3840, 2160, 5) and mirror != 0
+    g = group8
+    g.set_progressive(False)
+    g.set_sequence(1, False)
+    g.resize(w, h)
+    g.set_camera(z["c4_f2/cam"])
+    g.set_params(frame, mode, 0, 0, bounces, mirror, 1)
+    g.ring_create(2, 1, want_hits=True)
+    s = g.ring_submit(frame, 1)
+    _check(g.ring_read(s, 0, want_hits=True), z, "c4_f2", step)
+    # the crosshair pick out of the member chunk that holds the pixel
+    fh = z["c4_f2/first_hit"]
+    for x, y in ((1920, 1080), (8, 8 * 7), (3832, 2152)):
+        rgba, depth, hit = g.ring_read_pixel(s, 0, x, y)
+        assert (rgba == z["c4_f2/rgba"][y // step, x // step]).all()
+        assert np.float32(depth).view(np.uint32) == z["c4_f2/depth_bits"][y // step, x // step]
+        assert int(hit["pointer"]) == int(fh[y // step, x // step, 0])
+    g.ring_destroy()
+
+
+@pytest.mark.parametrize("nframes,last", [(64, 65), (32, 33)])
+def test_config5_through_the_8_way_split_equals_the_reference_shader(group8, nframes, last):
+    """config 5 as the reference can run it: the 64-frame cross-frame accumulation (svotrace.comp:712-719; frameNumber 2..65 on
+    a fresh image) at 1920 x 1080, every member carrying its stripes' whole sequence in ONE launch (svo_group_set_sequence) --
+    the shader's own frame 65 (and frame 33 via a 32-frame sequence), tests/golden/c5_progressive.npz"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_progressive.npz"))
+    n, w, h, mode = (int(v) for v in z["meta"])
+    st = int(z["step"][0])
+    assert (n, w, h, mode) == (8192, 1920, 1080, 0)
+    g = group8
+    g.resize(w, h)
+    g.set_camera(z["cam"])
+    g.set_params(2, mode, 0, 0, 2, 0, 1)
+    g.set_progressive(True)
+    g.set_sequence(nframes, True)
+    try:
+        g.ring_create(2, 1, want_hits=False)
+        s0 = g.ring_submit(2, 1)
+        s1 = g.ring_submit(2, 1)          # a second sequence in flight behind it, in the other slot
+        for s in (s0, s1):
+            got = g.ring_read(s, 0)
+            assert np.array_equal(got["rgba"][::st, ::st], z["f%d/rgba" % last]), ("rgba", last, s)
+            assert np.array_equal(got["depth"].view(np.uint32)[::st, ::st], z["f%d/depth_bits" % last]), ("depth", last, s)
+        g.ring_destroy()
+    finally:
+        g.set_progressive(False)
+        g.set_sequence(1, False)
+
+
+def test_group_on_two_physical_devices_equals_one_context():
+    """the multi-device half of svo_group_* (hipMemcpyPeer pool replication, hipMemcpyPeerAsync forwarding, RCCL send /
+    receive between communicators of different devices) needs two GPUs: skipped on the one-GPU boxes of this pool, ready for
+    the first box that has them.  Both exchanges, bit-exact against one context."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(512)
+    w, h = 640, 360
+    one = hiplib.HipContext(0)
+    want = {f: one.render(pool if f == 2 else None, w, h, CAMERAS["K1"], f, 0) for f in range(2, 10)}
+    one.close()
+    for exchange in (0, 1):
+        g = hiplib.HipGroup([0, 1])
+        try:
+            g.pool_upload(pool)
+            g.resize(w, h)
+            g.set_camera(CAMERAS["K1"])
+            g.set_params(2, 0, 0, 0, 2, 0, 1)
+            g.ring_create(2, 4, want_hits=True, exchange=exchange)
+            slots = [g.ring_submit(2, 4), g.ring_submit(6, 4)]
+            for b, s in enumerate(slots):
+                for k in range(4):
+                    _same(g.ring_read(s, k, want_hits=True), want[2 + 4 * b + k])
+            g.ring_destroy()
+        finally:
+            g.close()

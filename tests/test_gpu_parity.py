@@ -233,8 +233,11 @@ def test_config4_8192_4k_four_bounces_with_mirror(ctx, pool8192):
     _check_subsampled(ctx, pool8192, 3840, 2160, CAMERAS["K1"], 2, 0, 48, bounces=5, mirror_mask=0b1000)
 
 
-def test_config5_8192_1080p_multi_sample_accumulation(ctx, pool8192):
-    """BASELINE config 5 (reduced to 8 spp to keep the CPU oracle's share in seconds): accumulated GI."""
+def test_spp8_8192_1080p_the_library_s_own_reading_of_the_sample_loop(ctx, pool8192):
+    """NOT BASELINE config 5 (that is the reference's 64-frame accumulation: tests/test_c5_progressive.py, and through the
+    8-way split tests/test_gpu_group.py).  This is `spp`, the builder's reading of the shader's commented-out sample loop
+    (svotrace.comp:668-670; seeds frameNumber + sample, fp32 mean): 8 samples per pixel at 8192^3 / 1080p, HIP <-> oracle only
+    -- there is no reference behaviour to compare with."""
     from svo_raytracer_amd.cameras import CAMERAS
     ctx.set_pipeline(1)
     _check_subsampled(ctx, pool8192, 1920, 1080, CAMERAS["K2"], 2, 0, 40, spp=8)

@@ -348,3 +348,71 @@ def test_hostile_cameras_as_frames_of_one_launch_match_the_reference_shader():
     finally:
         c.close()
     assert ncases >= 300 and nlaunch < ncases / 2
+
+
+def test_a_ring_of_several_slots_runs_the_benchmarked_launch_shape_by_itself(ctx):
+    """What a drop-in host gets without any tuning call: a dispatch on the context's stream fills the GPU, the
+    submissions of a ring with more than one slot take 10 persistent waves per CU -- the shape bench.py's headline is
+    measured on; a positive svo_set_tuning value is used as given, 0 returns to the automatic choice.  Same bytes in every shape."""
+    import ctypes
+    from svo_raytracer_amd import hiplib
+    w, h = 1920, 1080                      # 32 400 tiles: more work than any launch shape has waves
+    ctx.set_pipeline(1)
+    ctx.set_tuning(0, 0)
+    ctx.resize(w, h)
+    want = _alone(ctx, w, h, 4, 0)
+    fill = ctx.launch_info()
+    assert fill["waves_per_cu"] >= 16 and fill["waves"] == fill["waves_per_cu"] * 256 and fill["round_threshold_sixteenths"] == 9
+    ctx.set_params(4, 0, 0, 0, 2, 0, 1)
+    ctx.ring_create(1, 2, want_hits=True)            # one slot = one launch at a time: fill
+    s = ctx.ring_submit(4, 2)
+    _eq(ctx.ring_read(s, 0, want_hits=True), want)
+    assert ctx.launch_info() == fill
+    ctx.ring_create(3, 2, want_hits=True)            # several slots: the benchmarked shape
+    s = ctx.ring_submit(4, 2)
+    _eq(ctx.ring_read(s, 0, want_hits=True), want)
+    assert ctx.launch_info() == {"waves": 2560, "waves_per_cu": 10, "round_threshold_sixteenths": 9}
+    _eq(_alone(ctx, w, h, 4, 0), want)              # a dispatch next to the ring still fills the GPU
+    assert ctx.launch_info() == fill
+    ctx.set_tuning(7, 11)                            # the caller's shape, everywhere
+    s = ctx.ring_submit(4, 1)
+    _eq(ctx.ring_read(s, 0, want_hits=True), want)
+    assert ctx.launch_info() == {"waves": 7 * 256, "waves_per_cu": 7, "round_threshold_sixteenths": 11}
+    ctx.set_tuning(0, 0)
+    s = ctx.ring_submit(4, 1)
+    ctx.ring_wait(s)
+    assert ctx.launch_info() == {"waves": 2560, "waves_per_cu": 10, "round_threshold_sixteenths": 9}
+    # the same through the JNI-typed export HipRenderer.lastLaunchWaves binds
+    f = getattr(hiplib.lib(), "Java_src_engine_HipRenderer_nLaunchInfo")
+    f.restype = ctypes.c_int32
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    wpc = ctypes.c_int32(0)
+    assert f(None, None, ctx._h.value, ctypes.addressof(wpc)) == 2560 and wpc.value == 10
+    ctx.ring_destroy()
+
+
+def test_a_continued_accumulation_is_refused_on_a_ring_of_several_slots(ctx):
+    """svotrace.comp:712-719 blends with the image the PREVIOUS dispatch left; on a ring of several slots that image is in
+    another slot: refused with a message instead of a silently different recurrence.  Fresh sequences and rings
+    of one slot go through."""
+    ctx.set_pipeline(1)
+    ctx.resize(160, 96)
+    ctx.set_params(2, 0, 0, 0, 2, 0, 1)
+    ctx.set_progressive(True)
+    try:
+        ctx.ring_create(2, 1)
+        ctx.set_sequence(1, False)
+        with pytest.raises(Exception, match="ONE slot"):
+            ctx.ring_submit(2, 1)
+        ctx.set_sequence(3, False)
+        with pytest.raises(Exception, match="ONE slot"):
+            ctx.ring_submit(2, 1)
+        ctx.set_sequence(3, True)
+        ctx.ring_wait(ctx.ring_submit(2, 1))
+        ctx.ring_create(1, 1)
+        ctx.set_sequence(2, False)
+        ctx.ring_wait(ctx.ring_submit(5, 1))
+    finally:
+        ctx.set_progressive(False)
+        ctx.set_sequence(1, False)
+        ctx.ring_destroy()

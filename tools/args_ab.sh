@@ -5,7 +5,7 @@ O=gpurun_out/args_ab.txt; : > $O
 for r in $(seq 1 ${ROUNDS:-6}); do
   for a in "$@"; do
     echo -n "[$a] " >> $O
-    timeout 600 python bench.py --steps 400 --warmup 24 --cpu-seconds 0 --isolated 0 --moving 0 $a 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['verified'])" >> $O 2>&1
+    timeout 600 python bench.py --steps 400 --warmup 24 --cpu-seconds 0 --isolated 0 --moving 0 --default-abi 0 --long-steps 0 $a 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['verified'])" >> $O 2>&1
   done
 done
 python - <<PY

@@ -34,9 +34,9 @@ SVO_BENCH_BACKEND=gloo SVO_BENCH_ONE_GPU=1 python -m torch.distributed.run --nno
 for n in 2 8; do SVO_BENCH_ONE_GPU=1 python bench.py --gpus $n --driver group --exchange copy $B --steps 100 --warmup 12 2>/dev/null | line > $O/bench_group${n}_one_gpu.json; done
 python tests/config_table.py > $O/config_table.md 2>&1; cat $O/config_table.md
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 12 --cpu-seconds 0 --verify 0 --isolated 0 --moving 0 > $GRAFT_REPO_ROOT/$O/trace.log 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_k20 -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --verify 0 --moving 0 > $GRAFT_REPO_ROOT/$O/trace_k20.log 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --verify 0 --inflight 1 --batch 1 --moving 0 > $GRAFT_REPO_ROOT/$O/trace1.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 12 --cpu-seconds 0 --verify 0 --isolated 0 --moving 0 --default-abi 0 --long-steps 0 > $GRAFT_REPO_ROOT/$O/trace.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_k20 -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --verify 0 --moving 0 --default-abi 0 --long-steps 0 > $GRAFT_REPO_ROOT/$O/trace_k20.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --verify 0 --inflight 1 --batch 1 --moving 0 --default-abi 0 --long-steps 0 > $GRAFT_REPO_ROOT/$O/trace1.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_c5 -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --steps 8 --warmup 2 --cpu-seconds 0 --verify 0 --isolated 0 > $GRAFT_REPO_ROOT/$O/trace_c5.log 2>&1
 cd $GRAFT_REPO_ROOT
 for t in trace trace_k20 trace1 trace_c5; do python tools/pmc_summary.py $O/$t > $O/${t}_summary.txt 2>&1; head -5 $O/${t}_summary.txt; tail -1 $O/$t.log | cut -c1-300 >> $O/${t}_summary.txt; rm -rf $O/$t; done

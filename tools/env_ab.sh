@@ -8,7 +8,7 @@ for r in $(seq 1 ${ROUNDS:-6}); do
   for v in "$@"; do
     echo -n "$v " >> $O
     if [ "$v" = "-" ]; then e=""; else e="$v"; fi
-    env $e timeout 600 python bench.py ${BENCH_ARGS:---steps 400 --warmup 24} --cpu-seconds 0 --moving 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['verified'])" >> $O 2>&1
+    env $e timeout 600 python bench.py ${BENCH_ARGS:---steps 400 --warmup 24} --cpu-seconds 0 --moving 0 --default-abi 0 --long-steps 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['verified'])" >> $O 2>&1
   done
 done
 python - <<PY

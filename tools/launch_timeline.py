@@ -1,5 +1,5 @@
 """Where a single-frame launch of the persistent kernel spends its time (SVO_STAMPS build): when the band counters run dry
-for the first / last wave, when the last wave ends.  SVO_HIP_LIB=.../libsvohip_stamps.so python tools/r03_timeline.py"""
+for the first / last wave, when the last wave ends.  SVO_HIP_LIB=.../libsvohip_stamps.so python tools/launch_timeline.py"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -51,7 +51,7 @@ def main():
         subprocess.call(["rm", "-rf", d])
         cmd = ["timeout", "-s", "KILL", "300", "rocprofv3", "--pmc"] + counters + \
               ["--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-               "--steps", str(8 * batch), "--warmup", str(batch), "--cpu-seconds", "0", "--verify", "0", "--isolated", "0", "--moving", "0"] + bench_args
+               "--steps", str(8 * batch), "--warmup", str(batch), "--cpu-seconds", "0", "--verify", "0", "--isolated", "0", "--moving", "0", "--default-abi", "0", "--long-steps", "0"] + bench_args
         with open(os.path.join(out_root, name + ".log"), "w") as lf:
             rc = subprocess.call(cmd, cwd="/tmp", env=env, stdout=lf, stderr=subprocess.STDOUT)
         print("pass %s rc %d" % (name, rc), flush=True)
