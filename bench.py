@@ -406,7 +406,9 @@ def run_default_abi(pool, W, H, cam, args, nbuf, batch, rays_per_frame, first_ti
             drain()
             return time.perf_counter() - t0
 
+        state["frame"] = 1002
         run(nbuf * batch)      # the new context's pool copy and table touched once, as the counting passes do for `value`'s context
+        state["frame"] = 2     # then the frame numbers of `value`'s own warm-up and timed region
         run(args.warmup)
         el = timed(args.steps)
         wpc = ctypes.c_int32(0)

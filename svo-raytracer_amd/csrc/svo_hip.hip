@@ -13,6 +13,9 @@
 
 #include "svo_fused.hip.h"
 #include "svo_persistent.hip.h"
+#if SVO_ASM_LOOP
+#include "svo_persist2.hip.h"
+#endif
 #include "svo_wavefront.hip.h"
 #include "svo_build.hip.h"
 #include "svo_beam.hip.h"
@@ -484,7 +487,7 @@ int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_sixteenths)
   if (!c || waves_per_cu < 0 || round_threshold_sixteenths < 0 || round_threshold_sixteenths > 15)
     return fail(c, SVO_E_INVALID, "svo_set_tuning: bad values");
   c->pb.waves_per_cu = waves_per_cu;
-  c->pb.thresh_num = round_threshold_sixteenths ? round_threshold_sixteenths : 9;
+  c->pb.thresh_num = round_threshold_sixteenths;   // 0 = the running kernel's own default
   c->wf.waves_per_cu = waves_per_cu;
   c->wf.thresh_num = round_threshold_sixteenths ? round_threshold_sixteenths : 12;
   return SVO_OK;
@@ -494,7 +497,7 @@ int svo_launch_info(svo_ctx *c, int *waves, int *waves_per_cu, int *round_thresh
   if (!c) return SVO_E_INVALID;
   if (waves) *waves = c->pb.last_blocks;
   if (waves_per_cu) *waves_per_cu = c->pb.last_per_cu;
-  if (round_threshold_sixteenths) *round_threshold_sixteenths = c->pb.thresh_num;
+  if (round_threshold_sixteenths) *round_threshold_sixteenths = c->pb.last_thresh;
   return SVO_OK;
 }
 

@@ -64,6 +64,9 @@ struct PersistArgs {
   uint32_t desc_count;
   // per-frame cameras and frame numbers of a batch (svo_ring_submit_cams), f.batch entries; only read by the kCams kernels
   const FrameVar *fvar;
+  // path records of the spare-ray kernel (svo_persist2.hip.h): kRecWaveWords words per persistent wave of the launch
+  uint32_t *prec;
+  int spare;   // 1 = launch the spare-ray kernel
 };
 
 // n / d by multiply-high with m = ceil(2^32 / d) = (2^32 + e) / d, 0 <= e < d (made on the host, udiv_magic): with
@@ -582,28 +585,55 @@ struct PersistBuffers {
   bool facc_used[kFaccSets] = {};
   size_t facc_floats = 0;   // floats in each colour-sum buffer
   int blocks = 0;
-  int thresh_num = 9;   // sixteenths (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 / 4.14 Grays/s, tools/history/sweep8.sh)
+  int thresh_num = 0;   // sixteenths; 0 = the running kernel's default: 9 for persist_kernel (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 /
+                        // 4.14 Grays/s, tools/history/sweep8.sh), SVO_SPARE_THRESH for the spare-ray kernel
+  int spare_mode = 0;   // 1 = the spare-ray kernel (svo_persist2.hip.h) on walkable pools (environment SVO_SPARE=1: round 5's
+                        // experiment, measured slower than persist_kernel with launches in flight); 0 = persist_kernel everywhere
+  uint32_t *prec[8] = {};      // path records of the spare-ray kernel, one buffer per counter set
+  size_t prec_words = 0;
+  int last_thresh = 9;
   int waves_per_cu = 0;      // 0 = automatic: as many as fit (occupancy query) for one launch at a time, kRingWavesPerCu for
                              // the submissions of a ring with more than one slot (in_ring, set around the launch by ring_submit)
   bool in_ring = false;
   int last_blocks = 0, last_per_cu = 0;   // shape of the last launch (svo_launch_info)
   int max_per_cu = 16, max_per_cu_desc = 16, cus = 256;   // resident waves per CU: byte walk / descriptor walk
+  int max_per_cu_spare = 0;                               // ... / the spare-ray kernel (0 = not asked yet)
   int cus_reserved = 0;   // CUs the launching stream may not use (svo_set_reserved_cus): fewer persistent waves
   unsigned launches = 0, frames = 0;
 };
 
 inline void persist_free(PersistBuffers &b) {
   if (b.heads) (void)hipFree(b.heads);
+  for (auto &p : b.prec) if (p) (void)hipFree(p);
   for (auto &f : b.facc) if (f) (void)hipFree(f);
   for (auto &e : b.head_done) if (e) (void)hipEventDestroy(e);
   for (auto &e : b.facc_done) if (e) (void)hipEventDestroy(e);
-  const int wpc = b.waves_per_cu, th = b.thresh_num;   // tuning survives a resize
+  const int wpc = b.waves_per_cu, th = b.thresh_num, sm = b.spare_mode;   // tuning survives a resize
   b = PersistBuffers();
-  b.waves_per_cu = wpc; b.thresh_num = th;
+  b.waves_per_cu = wpc; b.thresh_num = th; b.spare_mode = sm;
 }
+
+// the spare-ray kernel (svo_persist2.hip.h, included behind this file by svo_hip.hip)
+#if SVO_ASM_LOOP
+template <int kMode>
+inline void persist2_launch_mode(const PersistArgs &a, int blocks, hipStream_t stream);
+inline hipError_t persist2_occupancy(int *per_cu);
+#endif
+#ifndef SVO_SPARE_THRESH
+#define SVO_SPARE_THRESH 13
+#endif
+// SVO_SPARE_RECORDS: 0 = the two path records of a lane live in registers (18 each; the kernel then runs 4 waves per SIMD),
+// 1 = in global memory (6 waves per SIMD; measured: the records' traffic -- 144 bytes per ray written and read back, more
+// than the caches hold with six launches in flight -- costs more than the lanes gained: profiles/round5_experiments.txt)
+#ifndef SVO_SPARE_RECORDS
+#define SVO_SPARE_RECORDS 0
+#endif
 
 template <int kMode>
 inline void persist_launch_mode(const PersistArgs &a, int blocks, hipStream_t stream) {
+#if SVO_ASM_LOOP
+  if (a.spare) { persist2_launch_mode<kMode>(a, blocks, stream); return; }
+#endif
   if (a.fvar) {
     if (a.desc) hipLaunchKernelGGL((persist_kernel<kMode, DescWalk, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((persist_kernel<kMode, ByteWalk, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
@@ -689,9 +719,31 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     // experiment knobs (override svo_set_tuning)
     if (const char *e1 = getenv("SVO_PERSIST_WAVES_PER_CU")) b.waves_per_cu = atoi(e1);
     if (const char *e2 = getenv("SVO_PERSIST_THRESH")) b.thresh_num = atoi(e2);
+    if (const char *e3 = getenv("SVO_SPARE")) b.spare_mode = atoi(e3) != 0 ? 1 : 0;
+  }
+  // the spare-ray kernel walks the descriptor table in assembly: pools the table cannot state, and builds with hipcc's
+  // translation of the loop (SVO_ASM_LOOP=0), run persist_kernel
+  const bool spare_kernel = SVO_ASM_LOOP && b.spare_mode != 0 && desc != nullptr;
+#if SVO_ASM_LOOP
+  if (spare_kernel && b.max_per_cu_spare == 0) {
+    int per_cu = 0;
+    if (persist2_occupancy(&per_cu) != hipSuccess || per_cu < 1) per_cu = 16;
+    b.max_per_cu_spare = per_cu;
+  }
+#endif
+  if (spare_kernel && SVO_SPARE_RECORDS) {
+    const size_t need = (size_t)b.cus * (size_t)b.max_per_cu_desc * (size_t)(2 * 18 * 64);   // = kRecWaveWords per wave that fits
+    if (b.prec_words < need) {
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
+      for (auto &p : b.prec) { if (p) (void)hipFree(p); p = nullptr; }
+      b.prec_words = 0;
+      for (auto &p : b.prec)
+        if ((e = hipMalloc((void **)&p, need * sizeof(uint32_t))) != hipSuccess) return (int)e;
+      b.prec_words = need;
+    }
   }
   {
-    const int fill = desc ? b.max_per_cu_desc : b.max_per_cu;
+    const int fill = spare_kernel ? b.max_per_cu_spare : (desc ? b.max_per_cu_desc : b.max_per_cu);
     int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (b.in_ring ? std::min(kRingWavesPerCu, fill) : fill);
     b.blocks = (b.cus - b.cus_reserved) * per_cu;
     b.last_per_cu = per_cu;
@@ -736,7 +788,8 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.pool = pool; a.f = f; a.color = color; a.depth = depth; a.hits = hits; a.facc = facc; a.npix = npix;
   a.tiles_per_band = (f.ntiles + 7) / 8;
   a.rows_per_band = (f.tiles_y + 7) / 8;
-  a.thresh_num = b.thresh_num;
+  a.thresh_num = b.thresh_num > 0 ? b.thresh_num : (spare_kernel ? SVO_SPARE_THRESH : 9);
+  b.last_thresh = a.thresh_num;
   a.fold = fold;
   a.group = kFoldGroup;
   a.desc = desc; a.aux = aux; a.desc_count = desc_count;
@@ -757,6 +810,8 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   // are ordered by its stream, so they share the frame's set; only another frame's re-use waits (for the event)
   const int hset = (int)(frame_no % kHeadSets);
   a.heads = b.heads + (size_t)hset * kHeadWords;
+  a.prec = (spare_kernel && SVO_SPARE_RECORDS) ? b.prec[hset] : nullptr;   // (a counter set's launches are ordered by the set's event: so are its records)
+  a.spare = spare_kernel ? 1 : 0;
   if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
   for (int s = 0; s < (fold > 1 ? 1 : spp); s++) {
     a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;

@@ -12,13 +12,21 @@ python -m pytest tests -q -m gpu 2>&1 | tail -2 > $O/gpu_suite.txt; cat $O/gpu_s
 python tools/pmc_pass.py --tag $TAG -- > $O/pmc_pass.log 2>&1; tail -1 $O/pmc_pass.log | cut -c1-200
 python tools/pmc_pass.py --tag $TAG -- --inflight 1 --batch 1 > $O/pmc_pass1.log 2>&1; tail -1 $O/pmc_pass1.log | cut -c1-200
 cp gpurun_out/pmc_per_launch.json profiles/pmc_per_launch.json
+# lanes traversing per trip (an -DSVO_STAMPS=1 build of the same sources: make -C svo-raytracer_amd/csrc variant VARIANT=stamps EXTRA=-DSVO_STAMPS=1)
+if [ -f svo-raytracer_amd/csrc/libsvohip_stamps.so ]; then
+  STAMPS_JSON=1 STAMPS_WAVES=10 STAMPS_BATCH=4 SVO_HIP_LIB=$GRAFT_REPO_ROOT/svo-raytracer_amd/csrc/libsvohip_stamps.so python tools/stamps.py > $O/stamps.txt 2>&1
+  STAMPS_WAVES=10,24 STAMPS_BATCH=1 SVO_HIP_LIB=$GRAFT_REPO_ROOT/svo-raytracer_amd/csrc/libsvohip_stamps.so python tools/stamps.py >> $O/stamps.txt 2>&1
+  cp gpurun_out/stamps_per_launch.json profiles/stamps_per_launch.json; tail -3 $O/stamps.txt | cut -c1-250
+fi
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | line > $O/bench_driver_k20.json
-B="--cpu-seconds 0 --moving 0"
+B="--cpu-seconds 0 --moving 0 --default-abi 0 --long-steps 0"
 python bench.py --inflight 1 --batch 1 $B 2>/dev/null | line > $O/bench_inflight1.json
 python bench.py --camera-path orbit $B 2>/dev/null | line > $O/bench_orbit.json
 python bench.py --camera-path orbit --inflight 1 --batch 1 $B 2>/dev/null | line > $O/bench_orbit_inflight1.json
 SVO_DERIVED=0 python bench.py $B 2>/dev/null | line > $O/bench_recordwalk.json
+SVO_SPARE=1 python bench.py $B 2>/dev/null | line > $O/bench_spare_kernel.json
+SVO_SPARE=1 python bench.py --inflight 1 --batch 1 $B 2>/dev/null | line > $O/bench_spare_kernel_inflight1.json
 python bench.py --beam 1 $B 2>/dev/null | line > $O/bench_beam1.json
 python bench.py --mode 2 $B 2>/dev/null | line > $O/bench_mode2.json
 python bench.py --config C2 $B 2>/dev/null | line > $O/bench_C2.json

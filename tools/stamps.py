@@ -9,11 +9,21 @@ ctx = hiplib.HipContext(0)
 ctx.pool_upload(pool); ctx.resize(1920, 1080); ctx.set_camera(CAMERAS["K1"]); ctx.set_hit_records(False); ctx.set_pipeline(1)
 L = hiplib.lib()
 L.svo_debug_heads.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-for wpc in (10, 20):
-    t = 9
+import os, json
+OUT = {}
+BATCH = int(os.environ.get("STAMPS_BATCH", "1"))     # frames per launch (through a ring of one slot when > 1)
+for wpc in [int(v) for v in os.environ.get("STAMPS_WAVES", "10,20").split(",")]:
+    t = int(os.environ.get("STAMPS_THRESH", "0"))    # 0 = the kernel's own default
     ctx.set_tuning(wpc, t)
     ctx.set_params(2, 0, 0, 0, 2, 0, 1)
-    ms = ctx.time_frames(2, 1)   # 3 launches -> ring slots k, k+1, k+2; read all, take the last launch's set
+    if BATCH > 1:
+        ctx.ring_create(1, BATCH)
+        for k in range(2):
+            sl = ctx.ring_submit(2 + k * BATCH, BATCH)
+            ctx.ring_wait(sl)
+        ms = [ctx.ring_query(sl)["gpu_ms"] / BATCH]
+    else:
+        ms = ctx.time_frames(2, 1)   # 3 launches -> ring slots k, k+1, k+2; read all, take the last launch's set
     buf = np.zeros(96, dtype=np.uint32)
     L.svo_debug_heads(ctx._h, buf.ctypes.data)
     d = buf[0:12].view(np.uint64)
@@ -29,10 +39,25 @@ for wpc in (10, 20):
         cum = np.cumsum(full) / full.sum()
         print("  lanes traversing per trip: mean %.1f; trips with < 24 / 32 / 40 / 48 / 56 lanes: %.1f / %.1f / %.1f / %.1f / %.1f %%; idle lane-trips %.1f %% of 64 x trips" % (
             mean, 100 * cum[23], 100 * cum[31], 100 * cum[39], 100 * cum[47], 100 * cum[55], 100 * (1 - mean / 64)))
+        OUT["waves%d_batch%d" % (wpc, BATCH)] = {
+            "mean_lanes_traversing": round(float(mean), 2), "idle_lane_trips_pct": round(100 * (1 - mean / 64), 2),
+            "trips_below_40_lanes_pct": round(100 * float(cum[39]), 2), "trips_with_all_64_pct": round(100 * float(full[64] / full.sum()), 2),
+            "trips_per_wave": round(trips / nw, 1), "rounds_per_wave": round(float(d[2]) / nw, 1),
+            "what": "SVO_STAMPS build of the same sources: per trip of the assembly loop, lanes traversing; %d persistent waves per CU, "
+                    "%d frame(s) per launch, one launch at a time, 8192^3 / 1920x1080 / mode 0 / K1" % (wpc, BATCH)}
         print("  histogram by 8 lanes:", " ".join("%.1f" % (100 * full[i:i + 8].sum() / full.sum()) for i in range(0, 64, 8)), "| 64: %.1f" % (100 * full[64] / full.sum()))
     if d[3] == 0:   # assembly loop: trips are not counted inside the asm block
-        print("waves/cu", wpc, "thresh", t, "ms %.3f" % ms[-1], "rounds/wave %.1f  cyc/round: shade %.0f + refill+init %.0f + traversal %.0f" % (
-            d[2] / nw, d[4] / max(d[2], 1), (d[0] - d[4]) / max(d[2], 1), d[1] / max(d[2], 1)))
+        print("waves/cu", wpc, "thresh", t, "batch", BATCH, "ms/frame %.3f" % ms[-1], "rounds/wave %.1f trips/wave %.0f  cyc/round: round %.0f (shade part %.0f) + traversal %.0f; cyc/trip %.0f; round share %.1f %%" % (
+            d[2] / nw, trips / nw, float(d[0]) / max(d[2], 1), float(d[4]) / max(d[2], 1), float(d[1]) / max(d[2], 1), float(d[1]) / max(trips, 1),
+            100.0 * float(d[0]) / max(float(d[0]) + float(d[1]), 1)))
         continue
     print("waves/cu", wpc, "thresh", t, "ms %.3f" % ms[-1], "rounds/wave %.1f trips/wave %.1f  cyc/round %.0f (shade %.0f, refill+init %.0f)  cyc/trip %.0f (of which load issue->data %.0f)" % (
         d[2] / nw, d[3] / nw, d[0] / max(d[2], 1), d[4] / max(d[2], 1), (d[0] - d[4]) / max(d[2], 1), d[1] / max(d[3], 1), d[5] / max(d[3], 1)))
+
+if os.environ.get("STAMPS_JSON"):
+    import bench
+    key = "waves10_batch4" if "waves10_batch4" in OUT else sorted(OUT)[0]
+    e = dict(OUT[key], src_hash=bench.source_hash(), all=OUT)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "stamps_per_launch.json")
+    json.dump({"default": e}, open(path, "w"), indent=1)
+    print("wrote", path)
