@@ -407,7 +407,9 @@ def run_default_abi(pool, W, H, cam, args, nbuf, batch, rays_per_frame, first_ti
             return time.perf_counter() - t0
 
         state["frame"] = 1002
-        run(nbuf * batch)      # the new context's pool copy and table touched once, as the counting passes do for `value`'s context
+        # the new context's pool copy and table touched, and the GPU back at its clocks after the CPU-side verification of the
+        # legs before (`value`'s context had its counting passes for that): ~0.1 s of untimed frames
+        run(8 * nbuf * batch)
         state["frame"] = 2     # then the frame numbers of `value`'s own warm-up and timed region
         run(args.warmup)
         el = timed(args.steps)

@@ -57,6 +57,37 @@ namespace svo {
 #define SVO_HIST
 #endif
 
+// Where a level's stack entry lives.  The descriptor table only exists for pools of at most 13 levels (svo_derive.hip.h), so
+// this loop only ever pushes at scale 11..22 and the clamp of the record walk's loop (a deeper pool's pushes land on the last
+// level, identically in all pipelines) is dead here: the entry of scale s is at lds8 + (s - 11) * 512 = s * 512 + (lds8 - 11 * 512),
+// one shift-add on the scale instead of subtract, clamp, shift-add.  A POP that leaves the octree (scale 23: MISS) reads one row
+// past the column -- a row of the same wave's array or past it, where LDS reads return zero -- and drops what it read.
+// SVO_STACK_CLAMP=1 builds the clamped form (A/B).
+#ifndef SVO_STACK_CLAMP
+#define SVO_STACK_CLAMP 0
+#endif
+#if SVO_STACK_CLAMP
+#define SVO_PUSH_ADDR                                   \
+  "v_add_u32 %[t1], -11, %[scale]\n\t"                  \
+  "v_min_u32 %[t1], 11, %[t1]\n\t"                      \
+  "s_and_saveexec_b64 %[sb], vcc\n\t"                   \
+  "v_lshl_add_u32 v63, %[t1], 9, %[lds8]\n\t"
+#define SVO_POP_ADDR                                    \
+  "v_sub_u32 %[t2], 20, %[t0]\n\t"                      \
+  "v_xor_b32 %[scale], 31, %[t0]\n\t"                   \
+  "v_min_u32 %[t1], 11, %[t2]\n\t"                      \
+  "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"       \
+  "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
+#else
+#define SVO_PUSH_ADDR                                   \
+  "s_and_saveexec_b64 %[sb], vcc\n\t"                   \
+  "v_lshl_add_u32 v63, %[scale], 9, %[ldsb]\n\t"
+#define SVO_POP_ADDR                                    \
+  "v_xor_b32 %[scale], 31, %[t0]\n\t"                   \
+  "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"       \
+  "v_lshl_add_u32 %[t0], %[scale], 9, %[ldsb]\n\t"
+#endif
+
 // per-ray constants and state in the register layout of trav_loop2()
 struct TravRegs2 {
   float cx, bx;
@@ -120,6 +151,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
                                            unsigned long long act, const int threshold, const unsigned long long cone_lanes,
                                            uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
+  const uint32_t ldsb = lds8 - (uint32_t)kStackBase * 512u;   // + scale * 512 = the entry of that scale
   unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sm, sx;
   int cnt;
 #ifdef SVO_STAMPS
@@ -195,10 +227,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       SVO_COUNT("c2", "c3", "exec")
       "v_cmp_lt_f32 vcc, %[tcm], %[h]\n\t"                // tc_max < h: PUSH
       "v_mul_f32 v58, 0.5, v58\n\t"                       // half
-      "v_add_u32 %[t1], -11, %[scale]\n\t"
-      "v_min_u32 %[t1], 11, %[t1]\n\t"                    // stack level
-      "s_and_saveexec_b64 %[sb], vcc\n\t"
-      "v_lshl_add_u32 v63, %[t1], 9, %[lds8]\n\t"
+      SVO_PUSH_ADDR
       "ds_write2_b32 v63, %[self], %[tmax] offset1:1\n\t" // {parent state, t_max}
       "s_mov_b64 exec, %[sd]\n\t"
       "v_bfm_b32 %[t1], %[cs], 8\n\t"                     // the has bits of the children below cs
@@ -256,11 +285,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       // ---- POP (svotrace.comp:341-366)
       "v_or_b32 %[t0], 1, %[t0]\n\t"                      // (| 1 keeps ffbh defined)
       "v_ffbh_u32 %[t0], %[t0]\n\t"
-      "v_sub_u32 %[t2], 20, %[t0]\n\t"                    // scale - 11
-      "v_xor_b32 %[scale], 31, %[t0]\n\t"                 // scale = 31 - leading zeros
-      "v_min_u32 %[t1], 11, %[t2]\n\t"
-      "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"     // cell size = 2^(scale - 23)
-      "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
+      SVO_POP_ADDR
       "ds_read_b32 %[self], %[t0]\n\t"                    // a level this ray never pushed holds the zeros it started on:
       "ds_read_b32 %[tmax], %[t0] offset:4\n\t"           // state (0, 0) = descriptor 0, t_max 0
       "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
@@ -309,7 +334,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
 #endif
       : [cx] "v"(r.cx), [bx] "v"(r.bx),
         [cy] "v"(r.cyz.x), [cz] "v"(r.cyz.y), [by] "v"(r.byz.x), [bz] "v"(r.byz.y), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
-        [lds8] "v"(lds8), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
+        [lds8] "v"(lds8), [ldsb] "v"(ldsb), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
 #ifdef SVO_STAMPS
         , [lane] "v"(lane)
 #endif

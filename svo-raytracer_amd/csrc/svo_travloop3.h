@@ -114,6 +114,7 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
                                            unsigned long long &scone, unsigned long long &spare, unsigned long long &parked,
                                            unsigned long long &cpath, const uint2 rootd, uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
+  const uint32_t ldsb = lds8 - (uint32_t)kStackBase * 512u;   // + scale * 512 = the entry of that scale (svo_travloop2.h)
   unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sm, sx, sq, sw;
   int cnt, trig;
 #ifdef SVO_STAMPS
@@ -191,10 +192,7 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
       SVO_COUNT("c2", "c3", "exec")
       "v_cmp_lt_f32 vcc, %[tcm], %[h]\n\t"                // tc_max < h: PUSH
       "v_mul_f32 v58, 0.5, v58\n\t"                       // half
-      "v_add_u32 %[t1], -11, %[scale]\n\t"
-      "v_min_u32 %[t1], 11, %[t1]\n\t"                    // stack level
-      "s_and_saveexec_b64 %[sb], vcc\n\t"
-      "v_lshl_add_u32 v63, %[t1], 9, %[lds8]\n\t"
+      SVO_PUSH_ADDR
       "ds_write2_b32 v63, %[self], %[tmax] offset1:1\n\t" // {parent state, t_max}
       "s_mov_b64 exec, %[sd]\n\t"
       "v_bfm_b32 %[t1], %[cs], 8\n\t"                     // the has bits of the children below cs
@@ -247,11 +245,7 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
       // ---- POP (svotrace.comp:341-366)
       "v_or_b32 %[t0], 1, %[t0]\n\t"                      // (| 1 keeps ffbh defined)
       "v_ffbh_u32 %[t0], %[t0]\n\t"
-      "v_sub_u32 %[t2], 20, %[t0]\n\t"                    // scale - 11
-      "v_xor_b32 %[scale], 31, %[t0]\n\t"                 // scale = 31 - leading zeros
-      "v_min_u32 %[t1], 11, %[t2]\n\t"
-      "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"     // cell size = 2^(scale - 23)
-      "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
+      SVO_POP_ADDR
       "ds_read_b32 %[self], %[t0]\n\t"                    // a level this ray never pushed holds the zeros it started on:
       "ds_read_b32 %[tmax], %[t0] offset:4\n\t"           // state (0, 0) = descriptor 0, t_max 0
       "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
@@ -372,7 +366,7 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
 #ifdef SVO_STAMPS
         , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7), [hist] "+v"(hist)
 #endif
-      : [k005] "s"(0.05f), [lds8] "v"(lds8), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u),
+      : [k005] "s"(0.05f), [lds8] "v"(lds8), [ldsb] "v"(ldsb), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u),
         [thresh] "s"(threshold), [rootlo] "s"(rootd.x), [roothi] "s"(rootd.y), [bias] "s"(kIterBias), [kone] "s"(0x3f800000u)
 #ifdef SVO_STAMPS
         , [lane] "v"(lane)
