@@ -106,6 +106,10 @@ def parse(argv=None):
     ap.add_argument("--fallback", type=int, default=1, help="N > 1 without a launcher: when a rung (driver / exchange) fails, times out or "
                                                             "does not verify, go on with the next one in a fresh child process")
     ap.add_argument("--rung-timeout", type=float, default=480.0, help="N > 1 without a launcher: wall-clock limit of one rung, seconds")
+    ap.add_argument("--probe", type=int, default=1, help="N > 1 under a launcher (torch.distributed.run) with the default exchange: before this "
+                                                         "rank touches the GPU, a child process per rank runs a few small frames with the RCCL "
+                                                         "gather; if any rank's child fails or times out, all ranks go on with the copy exchange")
+    ap.add_argument("--probe-timeout", type=float, default=300.0, help="wall-clock limit of a probe child, seconds")
     ap.add_argument("--driver", choices=["torch", "group"], default="torch",
                     help="N > 1: torch = one process per GPU under torch.distributed (RCCL gather or IPC copies); group = ONE "
                          "process, the N GPUs behind the C ABI (svo_group_*: peer copies or RCCL send / receive inside the library)")
@@ -462,6 +466,51 @@ def stamps_for(key):
     return {k: v for k, v in e.items() if k != "src_hash"}
 
 
+def probe_command(args, exchange):
+    """A rank of the small run that tries an exchange out: 512^3, 640x360, 12 frames, verified against the oracle on rank 0."""
+    return [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--size", "512", "--width", "640", "--height", "360",
+            "--steps", "8", "--warmup", "4", "--inflight", "3", "--batch", "2", "--cpu-seconds", "0", "--moving", "0", "--default-abi", "0",
+            "--long-steps", "0", "--isolated", "0", "--probe", "0", "--driver", "torch", "--exchange", exchange]
+
+
+def probe_env(exchange, attempt):
+    """The environment of a probe child: this rank's RANK / LOCAL_RANK / WORLD_SIZE, a rendezvous of its own (the launcher's
+    store is the parent job's: the children meet at MASTER_PORT + 101 + attempt through a TCP store rank 0's child opens)."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 101 + attempt)
+    env["SVO_BENCH_CHILD"] = "1"
+    if exchange == "copy":
+        env["SVO_BENCH_BACKEND"] = "gloo"      # the copy exchange needs no collective on device memory: control plane only
+    return env
+
+
+def negotiate_exchange(args, dist, torch, runner=run_rung):
+    """N > 1 under a launcher, default exchange: decide -- before this process touches the GPU -- which exchange the ranks use.
+    Every rank starts a probe CHILD (a rank of a small job of its own: a few frames with the RCCL gather next to CU-masked
+    persistent launches, the combination that has never run between two devices); the ranks then agree over a CPU (gloo)
+    group: the RCCL gather if every rank's child came back clean, else the same question for the copy exchange, which needs no
+    collective.  Returns (exchange, backend, tried): backend "gloo" = the control plane stays on the CPU group made here."""
+    tried = []
+    dist.init_process_group("gloo")
+    for attempt, exchange in enumerate(("rccl", "copy")):
+        rc, line, err = runner(probe_command(args, exchange), args.probe_timeout, probe_env(exchange, attempt))
+        mine = rc == 0 and (line is None or line.get("verified") is not False)
+        t = torch.tensor([1 if mine else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(int(t.item()))
+        if ok:
+            break
+        how = "timed out after %d s" % int(args.probe_timeout) if rc is None else ("exit code %s" % rc if rc != 0 else
+                                                                                     ("verified: false" if not mine else "failed on another rank"))
+        tried.append({"driver": "torch", "exchange": exchange, "failed": "probe: " + how, "stderr_tail": err})
+    else:
+        exchange = "copy"      # nothing came back clean: the path that needs the least, and let the run itself say what is wrong
+    if exchange == "rccl":
+        dist.destroy_process_group()      # the run makes its NCCL group as always
+        return "rccl", "nccl", tried
+    return exchange, "gloo", tried
+
+
 def main(argv=None, ctx_factory=None):
     """ctx_factory: tests only -- a callable(local_rank) returning a CPU stand-in for hiplib.HipContext; the whole of main()
     then runs on CPU tensors under gloo (tests/test_bench_main_gloo.py), exercising the sharding, counting, timing
@@ -483,6 +532,13 @@ def main(argv=None, ctx_factory=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    negotiated = []
+    if (not stub and world > 1 and args.probe and not args.exchange_given and args.exchange == "rccl"
+            and os.environ.get("SVO_BENCH_CHILD") != "1" and os.environ.get("SVO_BENCH_BACKEND", "") != "gloo"):
+        # first contact with a node: try the exchange out in child processes before this one touches the GPU
+        args.exchange, backend, negotiated = negotiate_exchange(args, dist, torch)
+        if backend == "gloo":
+            os.environ["SVO_BENCH_BACKEND"] = "gloo"
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SVO hot path has no CPU fallback")
 
@@ -861,7 +917,7 @@ def main(argv=None, ctx_factory=None):
             "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
             "gather_ms": ring.gather_ms(),
-            "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if ngpu > 1 else None), "fallback_from": [],
+            "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if ngpu > 1 else None), "fallback_from": negotiated,
             "config": {
                 "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %s, camera %s, "
                             "%s, pipeline %d, %s" % (

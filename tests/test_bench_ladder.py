@@ -90,3 +90,64 @@ def test_a_child_of_the_ladder_does_not_walk_it(monkeypatch):
     except BaseException:       # no GPU here: the run itself stops at "bench.py needs a GPU"
         pass
     assert not called
+
+
+# ---- under a launcher (how the round driver starts N > 1) there is no parent to walk a ladder: the ranks try the exchange out in
+# child processes BEFORE they touch the GPU and agree over a CPU group (bench.negotiate_exchange)
+def _negotiate_worker(rank, world, port, fail_on, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench as b
+    args = b.parse(["--gpus", str(world), "--steps", "20", "--warmup", "5"])
+    seen = []
+
+    def runner(cmd, timeout_s, env):
+        ex = cmd[cmd.index("--exchange") + 1]
+        seen.append((ex, env["MASTER_PORT"], env.get("SVO_BENCH_BACKEND", ""), env.get("SVO_BENCH_CHILD"), "--probe" in cmd and cmd[cmd.index("--probe") + 1]))
+        assert not any(k.startswith("TORCHELASTIC_") for k in env)
+        if (rank, ex) in fail_on:
+            return (None, None, "hung in ncclCommInitRank") if ex == "rccl" else (1, None, "boom")
+        return 0, ({"verified": True} if rank == 0 else None), ""
+
+    exchange, backend, tried = b.negotiate_exchange(args, dist, torch, runner=runner)
+    with open(os.path.join(out_dir, "r%d.json" % rank), "w") as f:
+        json.dump({"exchange": exchange, "backend": backend, "tried": tried, "seen": seen, "initialized": dist.is_initialized()}, f)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _negotiate(tmp_path, fail_on):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_negotiate_worker, args=(2, port, fail_on, str(tmp_path)), nprocs=2, join=True)
+    return [json.load(open(tmp_path / ("r%d.json" % r))) for r in range(2)], port
+
+
+def test_ranks_under_a_launcher_keep_the_rccl_gather_when_every_probe_is_clean(tmp_path):
+    res, port = _negotiate(tmp_path, fail_on=set())
+    for r in res:
+        assert (r["exchange"], r["backend"], r["tried"]) == ("rccl", "nccl", []) and r["initialized"] is False
+        assert r["seen"] == [["rccl", str(port + 101), "", "1", "0"]]       # a rendezvous of its own, no probing inside the probe
+
+
+def test_one_rank_s_probe_hangs_and_all_ranks_agree_on_the_copy_exchange(tmp_path):
+    res, port = _negotiate(tmp_path, fail_on={(1, "rccl")})
+    for rank, r in enumerate(res):
+        assert (r["exchange"], r["backend"]) == ("copy", "gloo") and r["initialized"] is True    # the CPU group stays as control plane
+        assert [t["exchange"] for t in r["tried"]] == ["rccl"] and r["tried"][0]["failed"].startswith("probe: ")
+        assert [s[0] for s in r["seen"]] == ["rccl", "copy"] and r["seen"][1][1:3] == [str(port + 102), "gloo"]
+    assert "timed out" in res[1]["tried"][0]["failed"] and "another rank" in res[0]["tried"][0]["failed"]
+
+
+def test_nothing_probes_clean_the_run_goes_on_with_the_copy_exchange_and_says_so(tmp_path):
+    res, _ = _negotiate(tmp_path, fail_on={(0, "rccl"), (1, "copy")})
+    for r in res:
+        assert (r["exchange"], r["backend"]) == ("copy", "gloo") and [t["exchange"] for t in r["tried"]] == ["rccl", "copy"]

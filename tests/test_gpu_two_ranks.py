@@ -219,3 +219,22 @@ def test_config5_through_two_ranks_equals_the_reference_shader(tmp_path):
     rgba = r["color"].view(np.uint8).reshape(h, w, 4)
     assert np.array_equal(rgba[::st, ::st], z["f65/rgba"])
     assert np.array_equal(r["depth"].view(np.uint32)[::st, ::st], z["f65/depth_bits"])
+
+
+def test_ranks_under_the_launcher_negotiate_the_exchange_before_they_touch_the_gpu():
+    """How the round driver starts N > 1: `python -m torch.distributed.run ... bench.py --gpus N` with the default exchange.  Here
+    both ranks share GPU 0, where RCCL cannot make its communicator -- the situation a first contact with a node may produce for
+    other reasons: every rank's probe child fails (or is killed at its time limit), the ranks agree over gloo, and the run
+    itself goes through the copy exchange and says on its line what it tried (bench.negotiate_exchange)."""
+    env = dict(os.environ, SVO_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SVO_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "512", "--width", "640",
+           "--height", "360", "--steps", "12", "--warmup", "4", "--inflight", "2", "--batch", "2", "--cpu-seconds", "0", "--isolated", "0",
+           "--long-steps", "24", "--probe-timeout", "150"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["verified"] is True and line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["exchange"] == "copy" and [f["exchange"] for f in line["fallback_from"]] == ["rccl"], line["fallback_from"]
+    assert line["fallback_from"][0]["failed"].startswith("probe: ") and line["value"] > 0 and line["value_long_run"] > 0
