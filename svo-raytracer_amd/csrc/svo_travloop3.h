@@ -243,8 +243,7 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
-      "v_or_b32 %[t0], 1, %[t0]\n\t"                      // (| 1 keeps ffbh defined)
-      "v_ffbh_u32 %[t0], %[t0]\n\t"
+      "v_ffbh_u32 %[t0], %[t0]\n\t"                       // (the differing bits of a POP lane are never zero: d >> scale > 1)
       SVO_POP_ADDR
       "ds_read_b32 %[self], %[t0]\n\t"                    // a level this ray never pushed holds the zeros it started on:
       "ds_read_b32 %[tmax], %[t0] offset:4\n\t"           // state (0, 0) = descriptor 0, t_max 0
