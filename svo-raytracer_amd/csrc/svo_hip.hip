@@ -57,6 +57,7 @@ struct svo_ctx {
   float *own_depth = nullptr;
   uint4 *own_hits = nullptr;
   DeviceCounters *d_counters = nullptr;
+  float4 *d_ntab = nullptr;   // unit normal of every 16-bit normal code (svo_trav2.h::normal_table_kernel), made with the context
   // beam images: one per frame in flight, re-used round-robin behind the event of the frame that read it last
   static constexpr int kBeamSets = 8;
   float *d_beam[kBeamSets] = {};
@@ -136,6 +137,12 @@ int svo_create(int device, svo_ctx **out) {
     return SVO_E_HIP;
   }
   c->stream = c->own_stream;
+  // the normal table: 65 536 x 16 bytes, a function of nothing but the code
+  if (hipMalloc((void **)&c->d_ntab, 65536 * sizeof(float4)) == hipSuccess) {
+    hipLaunchKernelGGL(normal_table_kernel, dim3(256), dim3(256), 0, c->own_stream, c->d_ntab);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->own_stream) != hipSuccess) { (void)hipFree(c->d_ntab); c->d_ntab = nullptr; }
+  }
+  c->pb.ntab = c->d_ntab;   // (null: the kernels decode in place)
   *out = c;
   return SVO_OK;
 }
@@ -183,6 +190,7 @@ int svo_destroy(svo_ctx *c) {
   free_outputs(c);
   if (c->d_pool) (void)hipFree(c->d_pool);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_ntab) (void)hipFree(c->d_ntab);
   for (auto &e : c->beam_done) if (e) (void)hipEventDestroy(e);
   if (c->d_beam_live) (void)hipFree(c->d_beam_live);
   derive::free_table(c->dt);

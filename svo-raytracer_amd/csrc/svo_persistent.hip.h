@@ -67,6 +67,11 @@ struct PersistArgs {
   // path records of the spare-ray kernel (svo_persist2.hip.h): kRecWaveWords words per persistent wave of the launch
   uint32_t *prec;
   int spare;   // 1 = launch the spare-ray kernel
+  // row / column tables of the launch's frames (rc_table_kernel; only read by the kTab kernels): per frame rc_stride floats =
+  // W column records {ra, u} then H row records {a.x, a.y, a.z, rb, b.x, b.y, b.z, 0}
+  const float *rc;
+  uint32_t rc_stride;
+  const float4 *ntab;   // unit normals by 16-bit code (svo_trav2.h), or null
 };
 
 // n / d by multiply-high with m = ceil(2^32 / d) = (2^32 + e) / d, 0 <= e < d (made on the host, udiv_magic): with
@@ -187,7 +192,7 @@ struct DescWalk {
   uint2 rootd;
   __device__ __forceinline__ void setup(const PersistArgs &a) {
     pool = make_bufpool(a.pool, a.f.pool_len);
-    tab = make_desctab(a.desc, a.aux, a.desc_count);
+    tab = make_desctab(a.desc, a.aux, a.desc_count, a.ntab);
     const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(tab.rsrc, (int)kDescRoot, 0, 0);
     rootd = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)r.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y));
   }
@@ -256,7 +261,13 @@ template <> struct WalkWaves<DescWalk> { static constexpr int value = SVO_DERIVE
 // kCams: the frames of the batch carry their own camera and frameNumber (a.fvar) -- a kernel of its own, so that the
 // static-camera kernel keeps the camera in SGPRs from its kernel arguments
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-template <int kMode, class Walk, bool kCams = false>
+// kTab: the row and column parts of a new pixel's pure functions come from tables made once per launch (rc_table_kernel) instead
+// of being evaluated in every round for a third of the lanes -- of the primary direction (svotrace.comp:662-675) the two
+// divisions of the pixel centre and the six mixes along the left and right edge vectors (functions of the row) and the
+// horizontal fraction (of the column); of the pixel's random number (:26-29, :486) the two inner sin / fract chains (one a
+// function of the column and frameNumber, one of the row and frameNumber).  What stays in the round: three mixes, the
+// normalisation, the outer chain -- the same operations on the same values, so the same bits.
+template <int kMode, class Walk, bool kCams = false, bool kTab = false>
 __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(const PersistArgs a) {
   __shared__ typename Walk::Stack stk;
   const uint32_t lane = threadIdx.x;
@@ -451,7 +462,14 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
 #else
             pix = (uint32_t)frame_oy(f, tile_y, (int)(l >> 3)) * (uint32_t)f.width + (uint32_t)px;
 #endif
-            if (!kCams) d = primary_direction(f, px, py);
+            if (kTab) {
+              const float *fr = a.rc + (size_t)fi * a.rc_stride;
+              const float2 col = *(const float2 *)(fr + 2 * px);
+              const float *rowp = fr + ((2 * f.width + 3) & ~3) + 8 * py;   // (row records start on a 16-byte boundary)
+              const float4 ra4 = *(const float4 *)rowp, rb4 = *(const float4 *)(rowp + 4);
+              d = normalize3(mk(mix_g(ra4.x, rb4.x, col.y), mix_g(ra4.y, rb4.y, col.y), mix_g(ra4.z, rb4.z, col.y)));
+              if (kMode == 0) r = rand_of_dot(((float)px + col.x) * 12.9898f + ((float)py + ra4.w) * 78.233f);
+            } else if (!kCams) d = primary_direction(f, px, py);
 #if SVO_BAND_COLMAJOR
             seg = a.fold > 1 ? (si << 8) | (fi << 24) : 0u;
 #else
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             value = 0u;
             depth = 0.0f;
 #if SVO_BAND_COLMAJOR
-            if (kMode == 0 && !kCams) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + (int)fi + a.sample + (int)si));
+            if (kMode == 0 && !kCams && !kTab) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + (int)fi + a.sample + (int)si));
             if (kCams) { cam_frame = fi; cam_sample = a.sample + (int)si; cam_fresh = true; }
 #else
             if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)(f.frame_number + a.sample));
@@ -486,9 +504,9 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
               float cam[15];
 #pragma unroll
               for (int i = 0; i < 15; i++) cam[i] = __uint_as_float(raw[i]);
-              d = primary_direction_cam(cam, f.width, f.height, px, py);
+              if (!kTab) d = primary_direction_cam(cam, f.width, f.height, px, py);
               io = mk(cam[0], cam[1], cam[2]);
-              if (kMode == 0) r = pixel_rand((float)px, (float)py, (float)((int)raw[15] + cam_sample));
+              if (kMode == 0 && !kTab) r = pixel_rand((float)px, (float)py, (float)((int)raw[15] + cam_sample));
               cam_fresh = false;
             }
             todo &= ~__ballot(mine);
@@ -589,6 +607,11 @@ struct PersistBuffers {
                         // 4.14 Grays/s, tools/history/sweep8.sh), SVO_SPARE_THRESH for the spare-ray kernel
   int spare_mode = 0;   // 1 = the spare-ray kernel (svo_persist2.hip.h) on walkable pools (environment SVO_SPARE=1: round 5's
                         // experiment, measured slower than persist_kernel with launches in flight); 0 = persist_kernel everywhere
+  const float4 *ntab = nullptr;   // the context's normal table (made with the context; survives persist_free)
+  int ntab_mode = 1;              // environment SVO_NORMAL_TABLE=0: decode in place
+  int table_mode = 1;   // 1 = row / column tables + the kTab kernels where they apply (environment SVO_RC_TABLE=0: all in the rounds)
+  float *rc[8] = {};           // row / column tables, one buffer per counter set (a set's launches are ordered by its event)
+  size_t rc_floats[8] = {};
   uint32_t *prec[8] = {};      // path records of the spare-ray kernel, one buffer per counter set
   size_t prec_words = 0;
   int last_thresh = 9;
@@ -605,12 +628,41 @@ struct PersistBuffers {
 inline void persist_free(PersistBuffers &b) {
   if (b.heads) (void)hipFree(b.heads);
   for (auto &p : b.prec) if (p) (void)hipFree(p);
+  for (auto &p : b.rc) if (p) (void)hipFree(p);
   for (auto &f : b.facc) if (f) (void)hipFree(f);
   for (auto &e : b.head_done) if (e) (void)hipEventDestroy(e);
   for (auto &e : b.facc_done) if (e) (void)hipEventDestroy(e);
-  const int wpc = b.waves_per_cu, th = b.thresh_num, sm = b.spare_mode;   // tuning survives a resize
+  const int wpc = b.waves_per_cu, th = b.thresh_num, sm = b.spare_mode, tm = b.table_mode;   // tuning survives a resize
+  const float4 *nt = b.ntab;
+  const int nm = b.ntab_mode;
   b = PersistBuffers();
-  b.waves_per_cu = wpc; b.thresh_num = th; b.spare_mode = sm;
+  b.waves_per_cu = wpc; b.thresh_num = th; b.spare_mode = sm; b.table_mode = tm; b.ntab = nt; b.ntab_mode = nm;
+}
+
+// The row / column tables of a launch: per frame of the batch W + H threads.  A handful of workgroups: unlike a kernel of one
+// thread per pixel (tried and dropped, profiles/round5_experiments.txt) they find their slots next to the persistent waves of the
+// launches in flight as soon as a few of those retire.  The same device functions primary_direction_cam / pixel_rand call, on the
+// same values, in the same order.
+__global__ __launch_bounds__(256) void rc_table_kernel(const Frame f, const FrameVar *fvar, float *rc, const uint32_t stride, const int sample) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x), k = (int)blockIdx.y;
+  if (i >= f.width + f.height) return;
+  float *fr = rc + (size_t)k * stride;
+  const float *cam = fvar ? fvar[k].cam : f.cam;
+  const float seed2 = (float)((fvar ? fvar[k].frame_number : f.frame_number + k) + sample);
+  const float k0 = 0.1f * 78.233f, k1 = 0.02f * 78.233f;   // (pixel_rand's folded constants)
+  if (i < f.width) {
+    const float x = (float)i;
+    fr[2 * i] = rand_of_dot(x * 12.9898f + seed2 * k0);
+    fr[2 * i + 1] = (x + 0.5f) / (float)f.width;
+  } else {
+    const int y = i - f.width;
+    const float v = ((float)y + 0.5f) / (float)f.height;
+    float *row = fr + ((2 * f.width + 3) & ~3) + 8 * y;
+    row[0] = mix_g(cam[3], cam[6], v); row[1] = mix_g(cam[4], cam[7], v); row[2] = mix_g(cam[5], cam[8], v);
+    row[3] = rand_of_dot((float)y * 12.9898f + seed2 * k1);
+    row[4] = mix_g(cam[9], cam[12], v); row[5] = mix_g(cam[10], cam[13], v); row[6] = mix_g(cam[11], cam[14], v);
+    row[7] = 0.0f;
+  }
 }
 
 // the spare-ray kernel (svo_persist2.hip.h, included behind this file by svo_hip.hip)
@@ -634,6 +686,11 @@ inline void persist_launch_mode(const PersistArgs &a, int blocks, hipStream_t st
 #if SVO_ASM_LOOP
   if (a.spare) { persist2_launch_mode<kMode>(a, blocks, stream); return; }
 #endif
+  if (a.rc && a.desc) {   // (the tables are only made for launches that walk the descriptor table)
+    if (a.fvar) hipLaunchKernelGGL((persist_kernel<kMode, DescWalk, true, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((persist_kernel<kMode, DescWalk, false, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    return;
+  }
   if (a.fvar) {
     if (a.desc) hipLaunchKernelGGL((persist_kernel<kMode, DescWalk, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((persist_kernel<kMode, ByteWalk, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
@@ -720,6 +777,8 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     if (const char *e1 = getenv("SVO_PERSIST_WAVES_PER_CU")) b.waves_per_cu = atoi(e1);
     if (const char *e2 = getenv("SVO_PERSIST_THRESH")) b.thresh_num = atoi(e2);
     if (const char *e3 = getenv("SVO_SPARE")) b.spare_mode = atoi(e3) != 0 ? 1 : 0;
+    if (const char *e4 = getenv("SVO_RC_TABLE")) b.table_mode = atoi(e4) != 0 ? 1 : 0;
+    if (const char *e5 = getenv("SVO_NORMAL_TABLE")) b.ntab_mode = atoi(e5) != 0 ? 1 : 0;
   }
   // the spare-ray kernel walks the descriptor table in assembly: pools the table cannot state, and builds with hipcc's
   // translation of the loop (SVO_ASM_LOOP=0), run persist_kernel
@@ -812,11 +871,35 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   a.heads = b.heads + (size_t)hset * kHeadWords;
   a.prec = (spare_kernel && SVO_SPARE_RECORDS) ? b.prec[hset] : nullptr;   // (a counter set's launches are ordered by the set's event: so are its records)
   a.spare = spare_kernel ? 1 : 0;
+  // the row / column tables: launches that carry one sample per pixel (samples / sequences folded into a launch seed every
+  // sample of a pixel differently and keep computing in the round), on the descriptor walk, not the spare-ray kernel
+  a.rc = nullptr; a.rc_stride = 0;
+  a.ntab = b.ntab_mode != 0 ? b.ntab : nullptr;
+  if (b.table_mode != 0 && desc != nullptr && !spare_kernel && fold == 1) {
+    const size_t stride = (size_t)((2 * f.width + 3) & ~3) + 8 * (size_t)f.height, need = stride * (size_t)(f.batch > 1 ? f.batch : 1);
+    if (b.rc_floats[hset] < need) {   // grow all sets at once (one wait for the device, not one per set inside a run)
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;   // (launches in flight may still read the old tables)
+      for (int i = 0; i < kHeadSets; i++) {
+        if (b.rc[i]) (void)hipFree(b.rc[i]);
+        b.rc[i] = nullptr; b.rc_floats[i] = 0;
+      }
+      for (int i = 0; i < kHeadSets; i++) {
+        if ((e = hipMalloc((void **)&b.rc[i], need * sizeof(float))) != hipSuccess) return (int)e;
+        b.rc_floats[i] = need;
+      }
+    }
+    a.rc = b.rc[hset]; a.rc_stride = (uint32_t)stride;
+  }
   if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
   for (int s = 0; s < (fold > 1 ? 1 : spp); s++) {
     a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;
     if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
+    if (a.rc) {
+      const dim3 tgrid((unsigned)((f.width + f.height + 255) / 256), (unsigned)(f.batch > 1 ? f.batch : 1));
+      hipLaunchKernelGGL(rc_table_kernel, tgrid, dim3(256), 0, stream, f, fvar, b.rc[hset], a.rc_stride, s);
+      if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    }
     switch (f.render_mode) {
       case 0: persist_launch_mode<0>(a, blocks, stream); break;
       case 1: persist_launch_mode<1>(a, blocks, stream); break;

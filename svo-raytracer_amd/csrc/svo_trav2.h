@@ -14,12 +14,33 @@ namespace svo {
 struct DescTab {
   __amdgpu_buffer_rsrc_t rsrc;   // the descriptors, 8 bytes each, addressed by byte offset
   const uint2 *aux;              // {child-block base, tag mask} of every descriptor
+  const float4 *ntab;            // the unit normal of every 16-bit normal code (normal_table_kernel), or null: decode in place
 };
-__device__ __forceinline__ DescTab make_desctab(const uint2 *desc, const uint2 *aux, uint32_t count) {
+__device__ __forceinline__ DescTab make_desctab(const uint2 *desc, const uint2 *aux, uint32_t count, const float4 *ntab = nullptr) {
   DescTab t;
   t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)desc, 0, (int)(count * 8u), 0x00020000);
   t.aux = aux;
+  t.ntab = ntab;
   return t;
+}
+// the unit normal a node's 16-bit code stands for (svotrace.comp:405-421: three decimal digits - 5, normalised; 0 = no normal)
+__device__ __forceinline__ V3 decode_normal(const uint32_t raw) {
+  V3 n = mk(0.f, 0.f, 0.f);
+  if (raw != 0u) {
+    const int r = (int)raw;
+    const float nx = (float)((r % 10) - 5);
+    const float ny = (float)((((r % 100) - (r % 10)) / 10) - 5);
+    const float nz = (float)(((r - (r % 100)) / 100) - 5);
+    n = normalize3(mk(nx, ny, nz));
+  }
+  return n;
+}
+// all 65 536 of them, once per context: the same function on every code, so a look-up returns the bits the decode would
+__global__ void normal_table_kernel(float4 *t) {
+  const uint32_t raw = blockIdx.x * blockDim.x + threadIdx.x;
+  if (raw >= 65536u) return;
+  const V3 n = decode_normal(raw);
+  t[raw] = make_float4(n.x, n.y, n.z, 0.0f);
 }
 constexpr uint32_t kDescPhantom = 0u, kDescRoot = 8u;   // byte offsets of descriptors 0 and 1
 
@@ -163,14 +184,9 @@ __device__ __forceinline__ Cast cast_result2(const BufPool &pool, const DescTab 
   uint32_t raw = 0u;
   if (tag == 1u) raw = (rr.x >> 8) & 0xffffu;   // packed normal, u16 little-endian in bytes 1..2
   else if (tag != 3u) raw = rec2_mask_be(rr.y);
-  V3 n = mk(0.f, 0.f, 0.f);
-  if (raw != 0u) {
-    const int r = (int)raw;
-    const float nx = (float)((r % 10) - 5);
-    const float ny = (float)((((r % 100) - (r % 10)) / 10) - 5);
-    const float nz = (float)(((r - (r % 100)) / 100) - 5);
-    n = normalize3(mk(nx, ny, nz));
-  }
+  V3 n;
+  if (tab.ntab) { const float4 q = tab.ntab[raw]; n = mk(q.x, q.y, q.z); }
+  else n = decode_normal(raw);
   res.pointer = cptr;
   res.value = rr.x & 0xffu;
   res.raw = raw;

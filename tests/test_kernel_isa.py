@@ -46,13 +46,15 @@ def _kernel(kernels, *parts):
     return kernels[hit[0]]
 
 
+@pytest.mark.parametrize("tab", [0, 1])
 @pytest.mark.parametrize("cams", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
-def test_descriptor_walk_zeroes_a_new_ray_s_stack_column(disassembly, mode, cams):
+def test_descriptor_walk_zeroes_a_new_ray_s_stack_column(disassembly, mode, cams, tab):
     """trav_loop2's POP reads {descriptor, t_max} of its level unconditionally (no pushed-levels mask): every ray must
     start on a zeroed column = the reference's zero-initialised octstack (svotrace.comp:227).  12 levels of 8 bytes per
     lane: six ds_write2st64_b64 (or twelve ds_write_b64) next to the loop's one PUSH (ds_write2_b32)."""
-    ins = _kernel(disassembly, "persist_kernelILi%dE" % mode, "DescWalkELb%d" % cams)
+    # (tab: the kernels that read the launch's row / column tables -- what a launch without folded samples runs since round 5)
+    ins = _kernel(disassembly, "persist_kernelILi%dE" % mode, "DescWalkELb%dELb%dE" % (cams, tab))
     levels = 2 * ins.count("ds_write2st64_b64") + ins.count("ds_write_b64")
     assert levels >= 12, {k: ins.count(k) for k in set(ins) if k.startswith("ds_")}
     assert ins.count("ds_write2_b32") >= 1   # the PUSH
@@ -62,6 +64,7 @@ def test_persistent_kernels_use_no_scratch_beyond_the_known_spills(disassembly):
     """a tripwire, not a target: the descriptor walk's mode-0 kernel must keep its traversal loop free of scratch traffic
     (spills live in round code only) -- a `scratch_` / `buffer_..._offen` spill inside the loop body would show up as a
     jump in these counts"""
-    ins = _kernel(disassembly, "persist_kernelILi0E", "DescWalkELb0")
-    spills = sum(1 for i in ins if i.startswith("scratch_"))
-    assert spills < 120, spills
+    for tab in (0, 1):
+        ins = _kernel(disassembly, "persist_kernelILi0E", "DescWalkELb0ELb%dE" % tab)
+        spills = sum(1 for i in ins if i.startswith("scratch_"))
+        assert spills < 120, (tab, spills)

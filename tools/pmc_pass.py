@@ -6,7 +6,7 @@ one pass; PMC runs carry no trace flags; whole batches only, so that every launc
 writes gpurun_out/pmc_per_launch.json keyed like bench.py keys it, stamped with the hash of the kernel sources:
 bench.py only reports figures whose hash matches the sources it runs (copy the file to profiles/ to commit it).
 
-usage: python3 tools/pmc_pass.py [--kernel 'persist_kernel<0, svo::DescWalk, false>'] [--tag r04] -- <bench.py args>
+usage: python3 tools/pmc_pass.py [--kernel 'persist_kernel<0, svo::DescWalk, false, true>'] [--tag r05] -- <bench.py args>
 """
 import collections
 import csv
@@ -29,7 +29,7 @@ PASSES = [
 
 def main():
     argv = sys.argv[1:]
-    kernel, tag = "persist_kernel<0, svo::DescWalk, false>", "r04"
+    kernel, tag = "persist_kernel<0, svo::DescWalk, false, true>", "r05"
     while argv and argv[0] != "--":
         if argv[0] == "--kernel":
             kernel = argv[1]
