@@ -412,8 +412,9 @@ def run_default_abi(pool, W, H, cam, args, nbuf, batch, rays_per_frame, first_ti
 
         state["frame"] = 1002
         # the new context's pool copy and table touched, and the GPU back at its clocks after the CPU-side verification of the
-        # legs before (`value`'s context had its counting passes for that): ~0.1 s of untimed frames
-        run(8 * nbuf * batch)
+        # legs before (`value`'s context had its counting passes for that): ~0.5 s of untimed frames.  (With 0.1 s an 11 ms
+        # region of this leg read 6-8 % low and its 400-step region did not: profiles/round5_experiments.txt.)
+        run(int(os.environ.get("SVO_ABI_PREWARM", "1000")))
         state["frame"] = 2     # then the frame numbers of `value`'s own warm-up and timed region
         run(args.warmup)
         el = timed(args.steps)
