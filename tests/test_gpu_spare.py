@@ -87,3 +87,48 @@ def test_spare_kernel_renders_the_reference_shader_s_config3_and_config4_frames(
         ctx.ring_destroy()
     finally:
         ctx.close()
+
+
+def test_rounds_with_and_without_the_tables_leave_the_same_bytes(monkeypatch):
+    """Round 5's tables (row / column tables per launch, the context's normal table: DESIGN.md section 4) hold values the round
+    would compute with the same device functions; SVO_RC_TABLE=0 / SVO_NORMAL_TABLE=0 switch back to computing in the round.
+    Same frames either way -- every render mode, path options, the beam pre-pass, frames with their own cameras, odd image sizes
+    (rows of the tables that are not 16-byte multiples apart)."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(256)
+
+    def programme(ctx):
+        out = []
+        ctx.set_pipeline(1)
+        ctx.pool_upload(pool)
+        for (w, h) in ((200, 120), (201, 67)):
+            for mode, kw in ((0, {}), (1, {}), (2, {}), (3, {}), (0, dict(bounces=4, mirror_mask=0b1000)), (0, dict(use_beam=1))):
+                out.append(ctx.render(None, w, h, CAMERAS["K1"], 9, mode, **kw))
+        ctx.resize(201, 67)
+        ctx.set_params(2, 0, 0, 0, 2, 0, 1)
+        ctx.ring_create(2, 3, want_hits=True)
+        s = ctx.ring_submit_cams(np.stack([CAMERAS["K1"], CAMERAS["K2"], CAMERAS["K0"]]), [1, 1 << 24, -7])
+        out += [ctx.ring_read(s, k, want_hits=True) for k in range(3)]
+        s = ctx.ring_submit(40, 3)
+        out += [ctx.ring_read(s, k, want_hits=True) for k in range(3)]
+        ctx.ring_destroy()
+        return out
+
+    res = {}
+    for key, env in (("tables", {}), ("rounds", {"SVO_RC_TABLE": "0", "SVO_NORMAL_TABLE": "0"})):
+        for k in ("SVO_RC_TABLE", "SVO_NORMAL_TABLE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = hiplib.HipContext(0)
+        try:
+            res[key] = programme(ctx)
+        finally:
+            ctx.close()
+    assert len(res["tables"]) == len(res["rounds"]) == 18
+    for a, b in zip(res["tables"], res["rounds"]):
+        assert np.array_equal(a["rgba"], b["rgba"])
+        assert np.array_equal(a["depth"].view(np.uint32), b["depth"].view(np.uint32))
+        assert a["hits"].tobytes() == b["hits"].tobytes()
