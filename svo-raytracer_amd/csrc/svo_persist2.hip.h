@@ -1,4 +1,6 @@
-// svo_persist2.hip.h -- pipeline 1 on the descriptor table, with a spare ray per lane (the default since round 5).
+// svo_persist2.hip.h -- pipeline 1 on the descriptor table, with a spare ray per lane.  Round 5's experiment on the lanes that wait
+// for a round; OPT-IN (environment SVO_SPARE=1): it fills the lanes and saves a tenth of the vector instructions, but its state costs
+// two waves per SIMD and with launches in flight that costs more (-15 %: DESIGN.md section 4, profiles/round5_experiments.txt).
 //
 // persist_kernel (svo_persistent.hip.h) keeps 64 paths in flight per wave, one per lane; a lane whose ray has stopped waits
 // for the next round, and a round only pays once 7/16 of the lanes wait: 24.4 % of all lane-trips of the traversal loop are
@@ -10,14 +12,14 @@
 // stored pixel plus a fresh primary, and leaves it in the slot as the new spare.
 //
 // What outlives a cast of a path (direction, throughput mask, radiance, last normal / value, depth, pixel, segment, random
-// number: 18 words) is only needed when the path is shaded: it lives in a per-lane record in global memory -- two records
-// per lane, [wave][record][field][lane] words, written when a ray is set up and read when its result is shaded, coalesced
-// 256-byte rows -- not in registers across the traversal loop.  That keeps the kernel at persist_kernel's 6 waves per SIMD
-// with nine more registers of ray state.
+// number: 18 words) is only needed when the path is shaded.  Two records per lane; SVO_SPARE_RECORDS picks where they live: in
+// registers (default: 128 VGPRs, 4 waves per SIMD, the record of the slot's path picked by the lane set `cpath`), or in global
+// memory ([wave][record][field][lane] words, coalesced 256-byte rows; 80 VGPRs and 6 waves per SIMD, but 144 bytes per ray written
+// and read back: measured -26 %).
 //
 // Same arithmetic as persist_kernel statement for statement (the shading block below is its block, reading the cast from
 // a parked slot instead of the traversal registers): same bytes, checked by the whole parity suite on this kernel (it is
-// what pipeline 1 runs) and against persist_kernel itself (SVO_SPARE=0 / tests/test_gpu_spare.py).
+// what pipeline 1 ran while it was the default) and against persist_kernel itself (tests/test_gpu_spare.py).
 #pragma once
 #include "svo_persistent.hip.h"
 #include "svo_travloop3.h"
