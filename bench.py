@@ -404,11 +404,18 @@ def run_default_abi(pool, W, H, cam, args, nbuf, batch, rays_per_frame, first_ti
                     ok(nRingWait(j, b), "nRingWait")
 
         def timed(n):
+            # the region is bracketed like `value`'s: torch.cuda.synchronize() on both sides (a device-wide active wait;
+            # six hipEventSynchronize in a row -- nRingWait per slot -- wake up late often enough to cost an 11 ms region 6 %:
+            # profiles/round5_experiments.txt), the slots' own waits behind it for the bookkeeping
+            import torch
             drain()
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             run(n)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
             drain()
-            return time.perf_counter() - t0
+            return dt
 
         state["frame"] = 1002
         # the new context's pool copy and table touched, and the GPU back at its clocks after the CPU-side verification of the
@@ -426,6 +433,8 @@ def run_default_abi(pool, W, H, cam, args, nbuf, batch, rays_per_frame, first_ti
                "what": "a second context driven through the JNI-typed exports only (nCreate, nPoolUpload, nSetCamera, nResize, "
                        "nRingCreate(%d, %d, 0), nSetParams, nRingSubmit / nRingWait): no nSetTuning, nSetPipeline or nSetHitRecords "
                        "call -- the library's defaults" % (nbuf, batch)}
+        # the same region four more times: an 11 ms region's own spread on this box, next to its first reading
+        out["value_repeats"] = [round(rays_per_frame * args.steps / timed(args.steps) / 1e6, 2) for _ in range(4)] if args.steps <= 40 else None
         if args.long_steps > 0:
             el2 = timed(args.long_steps)
             out["value_long_run"] = round(rays_per_frame * args.long_steps / el2 / 1e6, 2)
