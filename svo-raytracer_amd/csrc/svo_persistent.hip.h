@@ -643,7 +643,11 @@ inline void persist_free(PersistBuffers &b) {
 // thread per pixel (tried and dropped, profiles/round5_experiments.txt) they find their slots next to the persistent waves of the
 // launches in flight as soon as a few of those retire.  The same device functions primary_direction_cam / pixel_rand call, on the
 // same values, in the same order.
-__global__ __launch_bounds__(256) void rc_table_kernel(const Frame f, const FrameVar *fvar, float *rc, const uint32_t stride, const int sample) {
+__global__ __launch_bounds__(256) void rc_table_kernel(const Frame f, const FrameVar *fvar, float *rc, const uint32_t stride, const int sample,
+                                                       uint32_t *heads) {
+  // (the launch's counter set is zeroed here too: one small kernel in front of the launch instead of a fill kernel and this one)
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kHeadWords; w += 256u) heads[w] = 0u;
   const int i = (int)(blockIdx.x * 256u + threadIdx.x), k = (int)blockIdx.y;
   if (i >= f.width + f.height) return;
   float *fr = rc + (size_t)k * stride;
@@ -893,13 +897,12 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
   for (int s = 0; s < (fold > 1 ? 1 : spp); s++) {
     a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;
-    if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     a.sample = s;
     if (a.rc) {
       const dim3 tgrid((unsigned)((f.width + f.height + 255) / 256), (unsigned)(f.batch > 1 ? f.batch : 1));
-      hipLaunchKernelGGL(rc_table_kernel, tgrid, dim3(256), 0, stream, f, fvar, b.rc[hset], a.rc_stride, s);
+      hipLaunchKernelGGL(rc_table_kernel, tgrid, dim3(256), 0, stream, f, fvar, b.rc[hset], a.rc_stride, s, a.heads);
       if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    }
+    } else if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     switch (f.render_mode) {
       case 0: persist_launch_mode<0>(a, blocks, stream); break;
       case 1: persist_launch_mode<1>(a, blocks, stream); break;
