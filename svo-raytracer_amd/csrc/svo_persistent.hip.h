@@ -643,29 +643,39 @@ inline void persist_free(PersistBuffers &b) {
 // thread per pixel (tried and dropped, profiles/round5_experiments.txt) they find their slots next to the persistent waves of the
 // launches in flight as soon as a few of those retire.  The same device functions primary_direction_cam / pixel_rand call, on the
 // same values, in the same order.
-__global__ __launch_bounds__(256) void rc_table_kernel(const Frame f, const FrameVar *fvar, float *rc, const uint32_t stride, const int sample,
-                                                       uint32_t *heads) {
+// Workgroups of ONE wave: a workgroup of four needs four free wave slots on one CU at the same moment, which CUs packed with
+// persistent waves offer much later than the single slot a lone wave needs.
+#ifndef SVO_RC_BLOCK
+#define SVO_RC_BLOCK 64
+#endif
+#ifndef SVO_RC_WAVES
+#define SVO_RC_WAVES 4    // workgroups per frame of the launch
+#endif
+__global__ __launch_bounds__(SVO_RC_BLOCK) void rc_table_kernel(const Frame f, const FrameVar *fvar, float *rc, const uint32_t stride, const int sample,
+                                                                uint32_t *heads) {
   // (the launch's counter set is zeroed here too: one small kernel in front of the launch instead of a fill kernel and this one)
   if (blockIdx.x == 0 && blockIdx.y == 0)
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kHeadWords; w += 256u) heads[w] = 0u;
-  const int i = (int)(blockIdx.x * 256u + threadIdx.x), k = (int)blockIdx.y;
-  if (i >= f.width + f.height) return;
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kHeadWords; w += (uint32_t)SVO_RC_BLOCK) heads[w] = 0u;
+  const int k = (int)blockIdx.y;
   float *fr = rc + (size_t)k * stride;
   const float *cam = fvar ? fvar[k].cam : f.cam;
   const float seed2 = (float)((fvar ? fvar[k].frame_number : f.frame_number + k) + sample);
   const float k0 = 0.1f * 78.233f, k1 = 0.02f * 78.233f;   // (pixel_rand's folded constants)
-  if (i < f.width) {
-    const float x = (float)i;
-    fr[2 * i] = rand_of_dot(x * 12.9898f + seed2 * k0);
-    fr[2 * i + 1] = (x + 0.5f) / (float)f.width;
-  } else {
-    const int y = i - f.width;
-    const float v = ((float)y + 0.5f) / (float)f.height;
-    float *row = fr + ((2 * f.width + 3) & ~3) + 8 * y;
-    row[0] = mix_g(cam[3], cam[6], v); row[1] = mix_g(cam[4], cam[7], v); row[2] = mix_g(cam[5], cam[8], v);
-    row[3] = rand_of_dot((float)y * 12.9898f + seed2 * k1);
-    row[4] = mix_g(cam[9], cam[12], v); row[5] = mix_g(cam[10], cam[13], v); row[6] = mix_g(cam[11], cam[14], v);
-    row[7] = 0.0f;
+  // a few waves per frame, each over a strided share of the W + H entries: the fewer workgroups, the sooner all of them have a slot
+  for (int i = (int)(blockIdx.x * (uint32_t)SVO_RC_BLOCK + threadIdx.x); i < f.width + f.height; i += (int)(gridDim.x * (uint32_t)SVO_RC_BLOCK)) {
+    if (i < f.width) {
+      const float x = (float)i;
+      fr[2 * i] = rand_of_dot(x * 12.9898f + seed2 * k0);
+      fr[2 * i + 1] = (x + 0.5f) / (float)f.width;
+    } else {
+      const int y = i - f.width;
+      const float v = ((float)y + 0.5f) / (float)f.height;
+      float *row = fr + ((2 * f.width + 3) & ~3) + 8 * y;
+      row[0] = mix_g(cam[3], cam[6], v); row[1] = mix_g(cam[4], cam[7], v); row[2] = mix_g(cam[5], cam[8], v);
+      row[3] = rand_of_dot((float)y * 12.9898f + seed2 * k1);
+      row[4] = mix_g(cam[9], cam[12], v); row[5] = mix_g(cam[10], cam[13], v); row[6] = mix_g(cam[11], cam[14], v);
+      row[7] = 0.0f;
+    }
   }
 }
 
@@ -899,8 +909,9 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;
     a.sample = s;
     if (a.rc) {
-      const dim3 tgrid((unsigned)((f.width + f.height + 255) / 256), (unsigned)(f.batch > 1 ? f.batch : 1));
-      hipLaunchKernelGGL(rc_table_kernel, tgrid, dim3(256), 0, stream, f, fvar, b.rc[hset], a.rc_stride, s, a.heads);
+      const unsigned per_frame = (unsigned)((f.width + f.height + SVO_RC_BLOCK - 1) / SVO_RC_BLOCK);
+      const dim3 tgrid(per_frame < (unsigned)SVO_RC_WAVES ? per_frame : (unsigned)SVO_RC_WAVES, (unsigned)(f.batch > 1 ? f.batch : 1));
+      hipLaunchKernelGGL(rc_table_kernel, tgrid, dim3(SVO_RC_BLOCK), 0, stream, f, fvar, b.rc[hset], a.rc_stride, s, a.heads);
       if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     } else if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
     switch (f.render_mode) {
