@@ -42,7 +42,8 @@ struct svo_ctx {
   int frame_number = 2, render_mode = 2, buffer_end = 0, use_beam = 0, bounces = 2, spp = 1, progressive = 0;
   int seq = 1, seq_fresh = 0;    // progressive: frames of the accumulation per dispatch, on a zeroed image or not (svo_set_sequence)
   const FrameVar *batch_cams = nullptr;     // host copy of the cameras / frame numbers of the batch being submitted
-  const FrameVar *batch_cams_dev = nullptr; // (svo_ring_submit_cams), and where the slot keeps them on the device
+  FrameVar *batch_cams_dev = nullptr;       // (svo_ring_submit_cams), and where the slot keeps them on the device
+  void *batch_cams_slot = nullptr;          // the ring slot being submitted (its staging copy: ring_copy_cams)
   int batch = 1;                 // frames per dispatch (svo_set_batch)
   uint64_t frame_stride = 0;     // elements between consecutive frames of a batch in each output
   uint32_t mirror_mask = 0;
@@ -747,6 +748,8 @@ static int launch_frame(svo_ctx *c, bool count) {
   return rc;
 }
 
+static int ring_copy_cams(void *ctx);
+
 static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *color, float *depth, uint4 *hits) {
   int rc = SVO_OK;
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
@@ -756,7 +759,8 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
     if (mode != 0 && (rc = ensure_derived(c)) != SVO_OK) return rc;
     const bool walk_table = mode != 0 && c->dt.ok;   // not derivable (deeper than 13 levels, cyclic): the records are walked
     rc = persist_launch(c->pb, c->d_pool, f, color, depth, hits, out_elems(c, f), c->stream, walk_table ? c->dt.desc : nullptr,
-                        walk_table ? c->dt.aux : nullptr, walk_table ? c->dt.count : 0u, c->batch_cams ? c->batch_cams_dev : nullptr);
+                        walk_table ? c->dt.aux : nullptr, walk_table ? c->dt.count : 0u, c->batch_cams ? c->batch_cams_dev : nullptr,
+                        c->batch_cams, ring_copy_cams, c);
     if (rc) return fail(c, SVO_E_HIP, std::string("persistent pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
@@ -928,6 +932,21 @@ int svo_ring_bind_slot(svo_ctx *c, int slot, void *color, void *depth, void *hit
   return SVO_OK;
 }
 
+// The staged host-to-device copy of a submission's per-frame cameras, on the slot's stream, out of a pinned copy that is
+// rewritten only once the copy that last read it has run.  Called by persist_launch for launches whose cameras do not travel in
+// the table kernel's arguments.  Returns a hipError_t as int.
+static int ring_copy_cams(void *ctx) {
+  svo_ctx *c = (svo_ctx *)ctx;
+  svo_ctx::RingSlot *s = (svo_ctx::RingSlot *)c->batch_cams_slot;
+  if (!s || !c->batch_cams || !s->d_fvar) return (int)hipErrorInvalidValue;
+  hipError_t e = hipEventSynchronize(s->fvar_copied);
+  if (e != hipSuccess) return (int)e;
+  memcpy(s->h_fvar, c->batch_cams, (size_t)c->batch * sizeof(FrameVar));
+  e = hipMemcpyAsync(s->d_fvar, s->h_fvar, (size_t)c->batch * sizeof(FrameVar), hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) e = hipEventRecord(s->fvar_copied, s->stream);
+  return (int)e;
+}
+
 // `cams`: null = nframes consecutive frames of the context's camera starting at frame_number (svo_ring_submit); else nframes
 // entries, every frame with its own camera and frameNumber (svo_ring_submit_cams)
 static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar *cams, int *slot, const char *who) {
@@ -961,21 +980,16 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
     memcpy(c->cam, cams[0].cam, sizeof c->cam);
     c->frame_number = cams[0].frame_number;
   } else if (cams) {
-    // the batch's cameras travel to the slot's table on its stream, in front of the launch that reads them, out of a
-    // pinned staging copy that is rewritten only once the copy that last read it has run
+    // the batch's cameras live in the slot's table on the device.  Launches with row / column tables carry them there inside the
+    // table kernel's arguments (up to kCamPack frames); the others get the staged copy of ring_copy_cams, enqueued by the
+    // launch itself in front of the first kernel that reads the table.
     if (!s.d_fvar) {
       e = hipMalloc((void **)&s.d_fvar, (size_t)c->ring_frames * sizeof(FrameVar));
       if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_fvar, (size_t)c->ring_frames * sizeof(FrameVar), hipHostMallocDefault);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&s.fvar_copied, hipEventDisableTiming);
-    } else {
-      e = hipEventSynchronize(s.fvar_copied);
+      if (e == hipSuccess) e = hipEventRecord(s.fvar_copied, s.stream);   // (so that the first wait below has something to wait for)
     }
-    if (e == hipSuccess) {
-      memcpy(s.h_fvar, cams, (size_t)nframes * sizeof(FrameVar));
-      e = hipMemcpyAsync(s.d_fvar, s.h_fvar, (size_t)nframes * sizeof(FrameVar), hipMemcpyHostToDevice, s.stream);
-    }
-    if (e == hipSuccess) e = hipEventRecord(s.fvar_copied, s.stream);
-    c->batch_cams = cams; c->batch_cams_dev = s.d_fvar;
+    c->batch_cams = cams; c->batch_cams_dev = s.d_fvar; c->batch_cams_slot = &s;
     c->frame_number = cams[0].frame_number;
   }
   if (e == hipSuccess) e = hipEventRecord(s.e0, s.stream);
@@ -1000,7 +1014,7 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
   c->stream = sv.stream; c->d_color = sv.col; c->d_depth = sv.dep; c->d_hits = sv.hit; c->external_outputs = sv.ext;
   c->batch = sv.batch; c->frame_stride = sv.stride; c->frame_number = sv.frame;
   memcpy(c->cam, sv.cam, sizeof c->cam);
-  c->batch_cams = nullptr; c->batch_cams_dev = nullptr;
+  c->batch_cams = nullptr; c->batch_cams_dev = nullptr; c->batch_cams_slot = nullptr;
   if (e != hipSuccess) return fail(c, SVO_E_HIP, std::string(who) + ": " + hipGetErrorString(e));
   if (rc) return rc;
   s.first_frame = cams ? cams[0].frame_number : frame_number; s.nframes = nframes; s.used = true;

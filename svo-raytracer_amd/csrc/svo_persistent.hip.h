@@ -651,15 +651,26 @@ inline void persist_free(PersistBuffers &b) {
 #ifndef SVO_RC_WAVES
 #define SVO_RC_WAVES 4    // workgroups per frame of the launch
 #endif
-__global__ __launch_bounds__(SVO_RC_BLOCK) void rc_table_kernel(const Frame f, const FrameVar *fvar, float *rc, const uint32_t stride, const int sample,
-                                                                uint32_t *heads) {
-  // (the launch's counter set is zeroed here too: one small kernel in front of the launch instead of a fill kernel and this one)
-  if (blockIdx.x == 0 && blockIdx.y == 0)
+// the counter set of a launch without tables: zeroed by a one-wave kernel (hipMemsetAsync is a fill kernel of wider workgroups here)
+__global__ __launch_bounds__(64) void zero_words_kernel(uint32_t *p, const uint32_t n) {
+  for (uint32_t w = threadIdx.x; w < n; w += 64u) p[w] = 0u;
+}
+constexpr int kCamPack = 8;   // per-frame cameras of a launch that travel in the table kernel's arguments (no copy in front of it)
+struct FrameVarPack { FrameVar v[kCamPack]; };
+__global__ __launch_bounds__(SVO_RC_BLOCK) void rc_table_kernel(const Frame f, FrameVar *fvar, float *rc, const uint32_t stride, const int sample,
+                                                                uint32_t *heads, const FrameVarPack pack, const int npack) {
+  // (the launch's counter set is zeroed here too: one small kernel in front of the launch instead of a fill kernel and this one;
+  // and with npack > 0 the launch's per-frame cameras arrive in `pack` and are written to the slot's table `fvar`, which the
+  // persistent kernel reads with a scalar load per frame: no host-to-device copy -- a blit kernel on this runtime -- in front either)
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
     for (uint32_t w = threadIdx.x; w < (uint32_t)kHeadWords; w += (uint32_t)SVO_RC_BLOCK) heads[w] = 0u;
+    for (uint32_t w = threadIdx.x; w < (uint32_t)npack * 16u; w += (uint32_t)SVO_RC_BLOCK)
+      ((uint32_t *)fvar)[w] = ((const uint32_t *)pack.v)[w];
+  }
   const int k = (int)blockIdx.y;
   float *fr = rc + (size_t)k * stride;
-  const float *cam = fvar ? fvar[k].cam : f.cam;
-  const float seed2 = (float)((fvar ? fvar[k].frame_number : f.frame_number + k) + sample);
+  const float *cam = npack > 0 ? pack.v[k].cam : (fvar ? fvar[k].cam : f.cam);
+  const float seed2 = (float)((npack > 0 ? pack.v[k].frame_number : (fvar ? fvar[k].frame_number : f.frame_number + k)) + sample);
   const float k0 = 0.1f * 78.233f, k1 = 0.02f * 78.233f;   // (pixel_rand's folded constants)
   // a few waves per frame, each over a strided share of the W + H entries: the fewer workgroups, the sooner all of them have a slot
   for (int i = (int)(blockIdx.x * (uint32_t)SVO_RC_BLOCK + threadIdx.x); i < f.width + f.height; i += (int)(gridDim.x * (uint32_t)SVO_RC_BLOCK)) {
@@ -767,7 +778,11 @@ inline bool persist_can_fold(const Frame &f, int n) {
 // `desc` / `aux` / `desc_count`: the interior-descriptor table of the pool (svo_derive.hip.h), or null = walk the records
 inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f, uint32_t *color, float *depth,
                           uint4 *hits, size_t out_npix, hipStream_t stream, const uint2 *desc = nullptr,
-                          const uint2 *aux = nullptr, uint32_t desc_count = 0, const FrameVar *fvar = nullptr) {
+                          const uint2 *aux = nullptr, uint32_t desc_count = 0, FrameVar *fvar = nullptr,
+                          const FrameVar *fvar_host = nullptr, int (*copy_cams)(void *) = nullptr, void *copy_arg = nullptr) {
+  // fvar: where the launch's per-frame cameras live on the device (null: one camera, f.cam); fvar_host: the same on the host.  They
+  // reach the device inside the table kernel's arguments when the launch has one and they fit (kCamPack), else through copy_cams
+  // (the caller's staged copy on `stream`), called here in front of the first kernel that reads them.
   // the colour-sum planes are indexed like the outputs: a batch needs room for all its frames
   const size_t npix = f.batch > 1 ? std::max(out_npix, (size_t)f.batch * (size_t)f.frame_stride) : out_npix;
   hipError_t e;
@@ -908,12 +923,21 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   for (int s = 0; s < (fold > 1 ? 1 : spp); s++) {
     a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;
     a.sample = s;
+    const int nb = f.batch > 1 ? f.batch : 1;
+    const bool packed = a.rc && fvar && fvar_host && nb <= kCamPack;
+    if (fvar && !packed && s == 0 && copy_cams) { const int rcc = copy_cams(copy_arg); if (rcc) return rcc; }
     if (a.rc) {
+      FrameVarPack pack;
+      if (packed) memcpy(pack.v, fvar_host, (size_t)nb * sizeof(FrameVar));
+      else memset(&pack, 0, sizeof pack);
       const unsigned per_frame = (unsigned)((f.width + f.height + SVO_RC_BLOCK - 1) / SVO_RC_BLOCK);
       const dim3 tgrid(per_frame < (unsigned)SVO_RC_WAVES ? per_frame : (unsigned)SVO_RC_WAVES, (unsigned)(f.batch > 1 ? f.batch : 1));
-      hipLaunchKernelGGL(rc_table_kernel, tgrid, dim3(SVO_RC_BLOCK), 0, stream, f, fvar, b.rc[hset], a.rc_stride, s, a.heads);
+      hipLaunchKernelGGL(rc_table_kernel, tgrid, dim3(SVO_RC_BLOCK), 0, stream, f, fvar, b.rc[hset], a.rc_stride, s, a.heads, pack, packed ? nb : 0);
       if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    } else if ((e = hipMemsetAsync(a.heads, 0, kHeadWords * sizeof(uint32_t), stream)) != hipSuccess) return (int)e;
+    } else {
+      hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, stream, a.heads, (uint32_t)kHeadWords);
+      if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    }
     switch (f.render_mode) {
       case 0: persist_launch_mode<0>(a, blocks, stream); break;
       case 1: persist_launch_mode<1>(a, blocks, stream); break;
