@@ -9,13 +9,17 @@
 // One 8-byte descriptor per PARENT STATE of the traversal, i.e. per pair (B = child-block base, M = tag mask) the
 // walk can hold (svotrace.comp:291: extractChild(parent.descriptor, parent.childPointer, ..., parent.leafMask) is a
 // function of exactly that pair):
-//   desc[i] = { byte offset of the descriptor of its first child that has a child block,
-//               ne | has << 8 }      ne bit c: child c's value byte != 0            (svotrace.comp:295)
-//                                    has bit c: child c is tag 0 with a non-zero cp  (svotrace.comp:311, extractNode)
+//   desc[i] = { byte offset of the descriptor of its first child the walk can descend into, minus 64,
+//               a nibble per child slot c }    0: child c's value byte == 0 -- empty               (svotrace.comp:295)
+//                                              1: not empty, nothing below it: a HIT               (svotrace.comp:311, extractNode)
+//                                              8 | rank: not empty, tag 0 with a non-zero cp -- the walk descends, into the
+//                                                        rank-th of this state's child descriptors
 //   aux[i]  = { B, M }               only read after the loop: hit pointer = B + offset(c, M) (svotrace.comp:381)
-// Children with a child block get consecutive descriptors (rank among the `has` bits), so DESCEND is
-// desc + 8 * popcount(has & below(c)); ADVANCE and HIT touch no memory at all; POP re-reads the ancestor's descriptor
-// (the LDS stack entry shrinks to {descriptor offset, t_max}).
+// Children the walk can descend into get consecutive descriptors, so DESCEND is desc.x + 8 * nibble -- one shift-add on the
+// nibble the trip has looked at anyway (rounds 2-4 kept the two bit masks ne | has << 8 and counted the has bits below c:
+// three more vector instructions in 93 % of the trips); ADVANCE and HIT touch no memory at all; POP re-reads the ancestor's
+// descriptor (the LDS stack entry shrinks to {descriptor offset, t_max}).  An EMPTY child with a child block (fuzzed pools)
+// is never descended into (svotrace.comp:295 comes first) and gets no descriptor.
 //
 // The table is an unrolling of the pool from the root pair, level by level (13 levels: a 13-level pool is the
 // reference's limit, MAX_DEPTH), so it states exactly what the byte walk would read -- also for pools no builder
@@ -37,6 +41,24 @@ namespace derive {
 constexpr uint32_t kPhantom = 0u, kRoot = 1u;
 constexpr int kLevels = kMaxDepth;   // parent states at depth 0..12
 constexpr size_t kHeadroom = 1u << 16;
+constexpr uint32_t kGroupBias = 64u;   // desc.x = 8 * (index of the first child descriptor) - 64: + 8 * (8 | rank) is the child's
+
+// the second word of a descriptor from the masks of its children (has is a subset of ne), and back
+__host__ __device__ inline uint32_t desc_word(uint32_t m_ne, uint32_t m_has) {
+  uint32_t w = 0, rank = 0;
+  for (uint32_t c = 0; c < 8; c++) {
+    if ((m_has >> c) & 1u) w |= (8u | rank++) << (4u * c);
+    else if ((m_ne >> c) & 1u) w |= 1u << (4u * c);
+  }
+  return w;
+}
+__host__ __device__ inline uint32_t desc_has(uint32_t w) {
+  uint32_t m = 0;
+  for (uint32_t c = 0; c < 8; c++) m |= ((w >> (4u * c + 3u)) & 1u) << c;
+  return m;
+}
+__host__ __device__ inline uint32_t desc_first(uint32_t x) { return (x + kGroupBias) >> 3; }   // index of the first child descriptor
+__host__ __device__ inline uint32_t desc_base(uint32_t first) { return first * 8u - kGroupBias; }
 
 struct Table {
   uint2 *desc = nullptr;
@@ -61,7 +83,8 @@ inline void free_table(Table &t) {
   t = Table();
 }
 
-// child c of the parent state (B, M): is it non-empty, does it have a child block, and which state is it as a parent
+// child c of the parent state (B, M): is it non-empty, can the walk descend into it (non-empty, with a child block), and which
+// state is it as a parent
 __device__ __forceinline__ void child_of(const BufPool &pool, uint32_t B, uint32_t M, uint32_t c, bool &ne, bool &has, uint2 &key) {
   const uint32_t tag = (M >> (2u * c)) & 3u;
   const uint32_t ptr = B + child_offset(M, c);
@@ -69,7 +92,7 @@ __device__ __forceinline__ void child_of(const BufPool &pool, uint32_t B, uint32
   const uint32_t hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pool.rsrc, (int)(ptr + 4u), 0, 0);
   ne = (lo & 0xffu) != 0u;
   const uint32_t cp = tag == 0u ? rec2_cp(lo, hi) : 0u;
-  has = cp != 0u;
+  has = ne && cp != 0u;
   key = make_uint2(ptr + cp, rec2_mask_be(hi));
 }
 
@@ -102,7 +125,7 @@ __global__ __launch_bounds__(256) void place_kernel(const uint8_t *pool_base, ui
   if (i >= n) return;
   const uint32_t m = masks[i], has = m >> 8;
   const uint32_t base = next + first[i];
-  if (c == 0u) desc[lo + i] = make_uint2(last_level ? 0u : base * 8u, m);
+  if (c == 0u) desc[lo + i] = make_uint2(last_level ? 0u : desc_base(base), desc_word(m & 0xffu, has));
   if (last_level || !((has >> c) & 1u)) return;
   const uint32_t j = base + (uint32_t)__builtin_popcount(has & ((1u << c) - 1u));
   if (j >= cap) return;
@@ -181,7 +204,7 @@ inline hipError_t build_table_sized(Table &t, const uint8_t *d_pool, uint32_t po
   auto rec_key = [&](uint32_t at, bool &ne, bool &has) {   // the record at byte `at`, read as an interior node
     ne = head[at] != 0;
     const uint32_t cp = ((uint32_t)head[at + 1] << 24) | ((uint32_t)head[at + 2] << 16) | ((uint32_t)head[at + 3] << 8) | head[at + 4];
-    has = cp != 0;
+    has = ne && cp != 0;
     return make_uint2(at + cp, ((uint32_t)head[at + 5] << 8) | head[at + 6]);
   };
   bool ne0, has0;
@@ -204,7 +227,7 @@ inline hipError_t build_table_sized(Table &t, const uint8_t *d_pool, uint32_t po
     uint2 rootd, rootkids_aux[8], rootkids_desc[8];
     if ((e = hipMemcpyAsync(&rootd, t.desc + kRoot, sizeof rootd, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-    const uint32_t nkids = (uint32_t)__builtin_popcount((rootd.y >> 8) & 0xffu), kid0 = rootd.x / 8u;
+    const uint32_t nkids = (uint32_t)__builtin_popcount(desc_has(rootd.y)), kid0 = desc_first(rootd.x);
     if (nkids) {
       if ((e = hipMemcpyAsync(rootkids_aux, t.aux + kid0, nkids * sizeof(uint2), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
       if ((e = hipMemcpyAsync(rootkids_desc, t.desc + kid0, nkids * sizeof(uint2), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -228,7 +251,7 @@ inline hipError_t build_table_sized(Table &t, const uint8_t *d_pool, uint32_t po
     }
     if ((uint64_t)end + nph > t.cap) { ok = false; *overflow = true; }
     if (ok) {
-      const uint2 phd = make_uint2(end * 8u, m_ne | (m_has << 8));
+      const uint2 phd = make_uint2(desc_base(end), desc_word(m_ne, m_has));
       if ((e = hipMemcpyAsync(t.desc + kPhantom, &phd, sizeof phd, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
       if (nph) {
         if ((e = hipMemcpyAsync(t.aux + end, ph_aux, nph * sizeof(uint2), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
@@ -310,11 +333,11 @@ __global__ __launch_bounds__(256) void recompute_kernel(const uint8_t *pool_base
   if (live) {
     i = list[k]; me = aux[i]; od = desc[i];
     child_of(pool, me.x, me.y & 0xffffu, c, ne, has, ck);
-    const uint32_t old_has = (od.y >> 8) & 0xffu;
+    const uint32_t old_has = desc_has(od.y);
     const bool old_c = ((old_has >> c) & 1u) != 0u;
     if (has != old_c) same = false;
     else if (has) {
-      jold = (od.x >> 3) + (uint32_t)__builtin_popcount(old_has & ((1u << c) - 1u));
+      jold = desc_first(od.x) + (uint32_t)__builtin_popcount(old_has & ((1u << c) - 1u));
       const uint2 oa = aux[jold];
       same = oa.x == ck.x && (oa.y & 0xffffu) == ck.y;
     }
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(256) void recompute_kernel(const uint8_t *pool_base
   if (!live) return;
   const uint32_t sh = threadIdx.x & 56u;
   const uint32_t m_ne = (uint32_t)(bn >> sh) & 0xffu, m_has = (uint32_t)(bh >> sh) & 0xffu;
-  const uint32_t masks = m_ne | (m_has << 8);
+  const uint32_t masks = desc_word(m_ne, m_has);
   if (((uint32_t)(bs >> sh) & 0xffu) == 0xffu) {   // same children with a child block, same states: the bits only
     if (c == 0u) desc[i] = make_uint2(od.x, masks);
     return;
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(256) void recompute_kernel(const uint8_t *pool_base
   if (c == 0u) base = atomicAdd(ctr + kCtrEnd, cnt);
   base = (uint32_t)__shfl((int)base, (int)(threadIdx.x & 56u));
   if ((uint64_t)base + cnt > cap) { if (c == 0u) atomicOr(ctr + kCtrFlags, kFlagTableFull); return; }
-  if (c == 0u) desc[i] = make_uint2(base * 8u, masks);
+  if (c == 0u) desc[i] = make_uint2(desc_base(base), masks);
   if (!has) return;
   const uint32_t j = base + (uint32_t)__builtin_popcount(m_has & ((1u << c) - 1u));
   if (same) { desc[j] = desc[jold]; aux[j] = aux[jold]; }   // (same && has: it was there before, with this (B', M'))
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(256) void unroll_new_kernel(const uint8_t *pool_bas
   if (!live) return;
   const uint32_t sh = threadIdx.x & 56u;
   const uint32_t m_ne = (uint32_t)(bn >> sh) & 0xffu, m_has = (uint32_t)(bh >> sh) & 0xffu;
-  const uint32_t masks = m_ne | (m_has << 8);
+  const uint32_t masks = desc_word(m_ne, m_has);
   const uint32_t d = (me.y >> 16) & 15u, cnt = (uint32_t)__builtin_popcount(m_has);
   if (d + 1u >= (uint32_t)kLevels) {   // the last level the walk can stand on: no child blocks below it
     if (c == 0u) { desc[i] = make_uint2(0u, masks); if (cnt) atomicOr(ctr + kCtrFlags, kFlagTooDeep); }
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(256) void unroll_new_kernel(const uint8_t *pool_bas
   if (c == 0u) base = atomicAdd(ctr + kCtrEnd, cnt);
   base = (uint32_t)__shfl((int)base, (int)(threadIdx.x & 56u));
   if ((uint64_t)base + cnt > cap) { if (c == 0u) atomicOr(ctr + kCtrFlags, kFlagTableFull); return; }
-  if (c == 0u) desc[i] = make_uint2(base * 8u, masks);
+  if (c == 0u) desc[i] = make_uint2(desc_base(base), masks);
   if (!has) return;
   const uint32_t j = base + (uint32_t)__builtin_popcount(m_has & ((1u << c) - 1u));
   aux[j] = make_uint2(ck.x, ck.y | ((d + 1u) << 16));

@@ -1,7 +1,7 @@
 // svo_trav2.h -- the cast over the interior-descriptor table (svo_derive.hip.h) instead of the pool's records.
 //
 // Same loop as svo_trav.h / svotrace.comp:262-369, same arithmetic in the same order; what changes is where the three
-// facts about the child come from: "empty" (svotrace.comp:295), "has a child block" (:311) are bits of the PARENT's
+// facts about the child come from: "empty" (svotrace.comp:295), "has a child block" (:311) are a nibble of the PARENT's
 // descriptor, already in registers; only a DESCEND (or a POP, which re-reads its ancestor's descriptor) loads -- one
 // aligned 8-byte descriptor.  The hit node's record (value, normal, pointer) is fetched once, after the loop.
 //   trav_step2()  the readable statement (SVO_ASM_LOOP=0 builds)
@@ -102,7 +102,8 @@ __device__ __forceinline__ int trav_step2(const DescTab &tab, WaveStack2 &stk, c
   const float tcz = t.pz * t.cz - t.bz;
   const float tc_max = vmin3(tcx, tcy, tcz);
   const uint32_t cs = t.idx ^ t.octant;
-  const bool ne = ((t.dhi >> cs) & 1u) != 0u, has = ((t.dhi >> (8u + cs)) & 1u) != 0u;
+  const uint32_t nib = (t.dhi >> (4u * cs)) & 15u;   // 0 empty, 1 not empty without a child block, 8 | rank: descend (svo_derive.hip.h)
+  const bool ne = nib != 0u, has = nib >= 8u;
   if (ne && t.t_min <= t.t_max) {
     if (t.scale == t.lod_scale) return ST_HIT;
     const float tv_max = vmin(t.t_max, tc_max);
@@ -119,7 +120,7 @@ __device__ __forceinline__ int trav_step2(const DescTab &tab, WaveStack2 &stk, c
         t.written |= 1u << lv;
       }
       t.h = tc_max;
-      t.self = t.dlo + 8u * (uint32_t)__builtin_popcount((t.dhi >> 8) & ((1u << cs) - 1u));
+      t.self = t.dlo + 8u * nib;   // (dlo = the first child descriptor's offset - 64)
       { const u32x2 dd = __builtin_amdgcn_raw_buffer_load_b64(tab.rsrc, (int)t.self, 0, 0); t.dlo = dd.x; t.dhi = dd.y; }
       t.idx = 0u;
       --t.scale;

@@ -16,7 +16,7 @@
 // Arithmetic, operand order and rounding are those of trav_step2() = trav_step() = svotrace.comp:262-369.
 //
 // Pinned registers: v[56:57] py,pz; v58 cell size; v[60:61] tcy,tcz; v[62:63] temporaries; v[64:65] the parent's
-// descriptor {first child descriptor, ne | has << 8}.
+// descriptor {first child descriptor - 64, a nibble per child} (svo_derive.hip.h).
 //
 // Which instructions: gfx950 issues a wave64 v_add / v_sub / v_mul / v_fma / logic op / v_mov / right shift / v_bitop3
 // every ~2.35 cycles per SIMD and every compare, v_cndmask, min / max, bit-field, shift-and-add, count or packed-f32
@@ -47,6 +47,30 @@ namespace svo {
   "buffer_load_dwordx2 v[64:65], %[self], %[rsd], 0 offen\n\t"
 #endif
 
+// The child slot times four: the scale register holds scale - 2 and a position has no bits below `scale`, so three bits from
+// scale - 2 on are the component's bit << 2.  (Right shifts by scale - 2 / - 3 / - 4 merged with two v_bitop3 bit selects -- 8
+// fast-class instructions instead of 5 slow + 1 -- measured +0.25 %, inside the spread: this part of the trip waits for the
+// descriptor anyway.  profiles/round5_experiments.txt)
+#define SVO_CHILD_SLOT                                                        \
+  "v_bfe_u32 %[t0], %[px], %[scale], 3\n\t"                                   \
+  "v_bfe_u32 %[t1], v56, %[scale], 3\n\t"                                     \
+  "v_bfe_u32 %[t2], v57, %[scale], 3\n\t"                                     \
+  "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"                                  \
+  "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n\t" /* 4 * idx */                    \
+  "v_xor_b32 %[cs], %[t0], %[oct]\n\t"       /* 4 * (idx ^ octant): where the child's nibble starts */
+// the child's nibble of the parent's descriptor: one bit-field extract (slow class), or shift + and (two fast-class instructions:
+// -0.35 %, inside the spread)
+#ifndef SVO_NIB_BFE
+#define SVO_NIB_BFE 1
+#endif
+#if SVO_NIB_BFE
+#define SVO_NIBBLE "v_bfe_u32 %[bit], v65, %[cs], 4\n\t"
+#else
+#define SVO_NIBBLE                            \
+  "v_lshrrev_b32 %[bit], %[cs], v65\n\t"      \
+  "v_and_b32 %[bit], 15, %[bit]\n\t"
+#endif
+
 #ifdef SVO_STAMPS
 #define SVO_HIST                                        \
   "s_mov_b64 exec, -1\n\t"                             \
@@ -68,13 +92,13 @@ namespace svo {
 #endif
 #if SVO_STACK_CLAMP
 #define SVO_PUSH_ADDR                                   \
-  "v_add_u32 %[t1], -11, %[scale]\n\t"                  \
+  "v_add_u32 %[t1], -9, %[scale]\n\t"                   \
   "v_min_u32 %[t1], 11, %[t1]\n\t"                      \
   "s_and_saveexec_b64 %[sb], vcc\n\t"                   \
   "v_lshl_add_u32 v63, %[t1], 9, %[lds8]\n\t"
 #define SVO_POP_ADDR                                    \
   "v_sub_u32 %[t2], 20, %[t0]\n\t"                      \
-  "v_xor_b32 %[scale], 31, %[t0]\n\t"                   \
+  "v_sub_u32 %[scale], 29, %[t0]\n\t"                   \
   "v_min_u32 %[t1], 11, %[t2]\n\t"                      \
   "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"       \
   "v_lshl_add_u32 %[t0], %[t1], 9, %[lds8]\n\t"
@@ -83,7 +107,7 @@ namespace svo {
   "s_and_saveexec_b64 %[sb], vcc\n\t"                   \
   "v_lshl_add_u32 v63, %[scale], 9, %[ldsb]\n\t"
 #define SVO_POP_ADDR                                    \
-  "v_xor_b32 %[scale], 31, %[t0]\n\t"                   \
+  "v_sub_u32 %[scale], 29, %[t0]\n\t"                   \
   "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"       \
   "v_lshl_add_u32 %[t0], %[scale], 9, %[ldsb]\n\t"
 #endif
@@ -92,24 +116,26 @@ namespace svo {
 struct TravRegs2 {
   float cx, bx;
   f32x2 cyz, byz;
-  uint32_t octant;
+  uint32_t octant;    // the mirror mask of svotrace.comp:239-252, times four (see cs)
   float px;
   float py, pz;   // (two floats, not a pair: a vector member tied to v[56:57] kept px / py / pz in scratch memory around every loop)
   float t_min, t_max, sexp, h;
-  int scale;
-  uint32_t cs;        // child slot of the last trip (index ^ octant): the slot a stopped lane stopped on
+  int scale;          // scale - 2: three bits of a position component from there are its child-slot bit times four
+  uint32_t cs;        // 4 * child slot of the last trip (index ^ octant) = where the child's nibble starts in the parent's
+                      // descriptor: the slot a stopped lane stopped on
   uint32_t self;      // byte offset of the parent state's descriptor
   uint32_t dlo, dhi;  // that descriptor
   uint32_t written, iter;
-  int lod_scale;
+  int lod_scale;      // minus two, like scale
 };
+constexpr int kScaleBias = 2;
 
 // set-up part of the cast (svotrace.comp:221-260); `rootd` = the root's descriptor, fetched once per wave
 __device__ __forceinline__ int trav_init_regs2(const uint2 rootd, TravRegs2 &t, V3 o, V3 d, const bool cone,
                                                const float t_start = 0.0f) {
   (void)cone;   // which lanes carry cone (secondary) rays is a lane set the caller passes to trav_loop2
-  t.iter = 0; t.cs = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth;
-  t.scale = kMaxScale - 1; t.sexp = 0.5f;
+  t.iter = 0; t.cs = 0; t.written = 0; t.lod_scale = kMaxScale - kMaxDepth - kScaleBias;
+  t.scale = kMaxScale - 1 - kScaleBias; t.sexp = 0.5f;
   t.self = kDescRoot; t.dlo = rootd.x; t.dhi = rootd.y;
   if (all_nan(o) || all_nan(d)) {  // quirk Q7: the reference spins to the cap, iter = 1501
     t.iter = kMaxIter + 1u; t.t_min = 0.0f; t.t_max = 0.0f; t.h = 0.0f; t.octant = 0;
@@ -124,9 +150,9 @@ __device__ __forceinline__ int trav_init_regs2(const uint2 rootd, TravRegs2 &t, 
   t.cyz.y = 1.0f / -__builtin_fabsf(d.z);
   t.bx = t.cx * o.x; t.byz.x = t.cyz.x * o.y; t.byz.y = t.cyz.y * o.z;
   t.octant = 0;
-  if (d.x > 0.0f) { t.octant ^= 1u; t.bx = 3.0f * t.cx - t.bx; }
-  if (d.y > 0.0f) { t.octant ^= 2u; t.byz.x = 3.0f * t.cyz.x - t.byz.x; }
-  if (d.z > 0.0f) { t.octant ^= 4u; t.byz.y = 3.0f * t.cyz.y - t.byz.y; }
+  if (d.x > 0.0f) { t.octant ^= 4u; t.bx = 3.0f * t.cx - t.bx; }
+  if (d.y > 0.0f) { t.octant ^= 8u; t.byz.x = 3.0f * t.cyz.x - t.byz.x; }
+  if (d.z > 0.0f) { t.octant ^= 16u; t.byz.y = 3.0f * t.cyz.y - t.byz.y; }
   t.t_min = vmax3(2.0f * t.cx - t.bx, 2.0f * t.cyz.x - t.byz.x, 2.0f * t.cyz.y - t.byz.y);
   t.t_max = vmin3(t.cx - t.bx, t.cyz.x - t.byz.x, t.cyz.y - t.byz.y);
   t.t_min = vmax(t.t_min, 0.0f);
@@ -140,7 +166,7 @@ __device__ __forceinline__ int trav_init_regs2(const uint2 rootd, TravRegs2 &t, 
 }
 
 __device__ __forceinline__ Cast trav_result_regs2(const BufPool &pool, const DescTab &tab, const TravRegs2 &t, int status) {
-  return cast_result2(pool, tab, status, t.self, t.cs, t.octant, t.iter, t.t_min, t.sexp, t.scale, t.px, t.py, t.pz);
+  return cast_result2(pool, tab, status, t.self, t.cs >> 2, t.octant >> 2, t.iter, t.t_min, t.sexp, t.scale + kScaleBias, t.px, t.py, t.pz);
 }
 
 // Run trips until at most `threshold` lanes of `act` (the lanes with status == ST_ACTIVE) are still traversing.
@@ -151,7 +177,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
                                            unsigned long long act, const int threshold, const unsigned long long cone_lanes,
                                            uint32_t *mix = nullptr) {
   const uint32_t lds8 = lds_offset(&stk.pm[lane]);
-  const uint32_t ldsb = lds8 - (uint32_t)kStackBase * 512u;   // + scale * 512 = the entry of that scale
+  const uint32_t ldsb = lds8 - ((uint32_t)kStackBase - 2u) * 512u;   // + (scale - 2) * 512 = the entry of that scale
   unsigned long long sv, sa, sb, sc, sd, se, sf, sg, sh, sp, sm, sx;
   int cnt;
 #ifdef SVO_STAMPS
@@ -173,12 +199,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       SVO_COUNT("c0", "c1", "exec")
       SVO_HIST
       // ---- child slot (bit `scale` of the three position components), iteration cap (svotrace.comp:263-266)
-      "v_bfe_u32 %[t0], %[px], %[scale], 1\n\t"
-      "v_bfe_u32 %[t1], v56, %[scale], 1\n\t"
-      "v_bfe_u32 %[t2], v57, %[scale], 1\n\t"
-      "v_lshl_or_b32 %[t0], %[t1], 1, %[t0]\n\t"
-      "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n\t"                  // idx = x | y << 1 | z << 2
-      "v_xor_b32 %[cs], %[t0], %[oct]\n\t"                        // cs = idx ^ octant
+      SVO_CHILD_SLOT
       "v_add_co_u32 %[iter], vcc, 1, %[iter]\n\t"                 // iter++ on a counter biased by 2^32 - 1501: the carry is "iter > 1500"
       "s_cmp_lg_u64 vcc, 0\n\t"
       "s_cbranch_scc1 Lcap%=\n"                                   // rare, out of line
@@ -194,7 +215,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_and_b64 vcc, vcc, %[conem]\n\t"                          // ... on a cone (secondary) ray: LOD 11 from here on (sticky)
       "v_cmp_le_f32_e64 %[sa], %[tmin], %[tmax]\n\t"              // t_min <= t_max
       "v_min3_f32 %[tcm], %[tcx], v60, v61\n\t"                   // tc_max
-      "v_cndmask_b32_e64 %[lod], %[lod], 12, vcc\n\t"
+      "v_cndmask_b32_e64 %[lod], %[lod], 10, vcc\n\t"                // (12 - 2)
       "v_min_f32 %[t3], %[tmax], %[tcm]\n\t"                      // tv_max
       "v_cmp_eq_u32_e64 %[sb], %[scale], %[lod]\n\t"              // at the LOD scale
       "v_cmp_le_f32_e64 %[sc], %[tmin], %[t3]\n\t"                // t_min <= tv_max
@@ -209,10 +230,9 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       // an axis that steps out of the lower half leaves the parent: POP (svotrace.comp:341; idx & step after the flip =
       // step & ~idx before it) -- on lane sets, no step mask in a register
       "s_waitcnt vmcnt(0)\n\t"
-      "v_lshrrev_b32 %[bit], %[cs], v65\n\t"            // bit cs of the ne byte -> bit 0, of the has byte -> bit 8
-      "v_and_b32 %[bit], %[k101], %[bit]\n\t"
-      "v_cmp_ne_u32_sdwa %[sa], %[bit], %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // child not empty
-      "v_cmp_ne_u32_sdwa vcc, %[bit], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"     // child has a child block
+      SVO_NIBBLE                                          // the child's nibble: 0 empty, 1 not empty, 8 | rank with a child block
+      "v_cmp_ne_u32_e64 %[sa], 0, %[bit]\n\t"           // child not empty
+      "v_cmp_lt_u32 vcc, 7, %[bit]\n\t"                 // child has a child block
       // lane sets
       "s_and_b64 %[sd], %[sd], vcc\n\t"
       "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = not empty & in range & !at LOD & inside & child block
@@ -230,10 +250,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       SVO_PUSH_ADDR
       "ds_write2_b32 v63, %[self], %[tmax] offset1:1\n\t" // {parent state, t_max}
       "s_mov_b64 exec, %[sd]\n\t"
-      "v_bfm_b32 %[t1], %[cs], 8\n\t"                     // the has bits of the children below cs
-      "v_and_b32 %[t1], %[t1], v65\n\t"
-      "v_bcnt_u32_b32 %[t1], %[t1], 0\n\t"
-      "v_lshl_add_u32 %[self], %[t1], 3, v64\n\t"         // the child's descriptor
+      "v_lshl_add_u32 %[self], %[bit], 3, v64\n\t"        // the child's descriptor: (first - 64) + 8 * (8 | rank)
       SVO_DESC_LOAD_D
       "v_mul_f32 %[t0], %[cx], v58\n\t"
       "v_mul_f32 v62, %[cy], v58\n\t"
@@ -277,8 +294,8 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "v_xor_b32 %[t0], %[t0], %[px]\n\t"
       "v_bitop3_b32 %[t0], %[t0], %[t1], v56 bitop3:0xf6\n\t"   // a | (b ^ c)
       "v_bitop3_b32 %[t0], %[t0], %[t2], v57 bitop3:0xf6\n\t"
-      "v_lshrrev_b32 %[t1], %[scale], %[t0]\n\t"
-      "v_cmp_lt_u32_e64 %[sp], 1, %[t1]\n\t"
+      "v_lshrrev_b32 %[t1], %[scale], %[t0]\n\t"        // (by scale - 2)
+      "v_cmp_lt_u32_e64 %[sp], 7, %[t1]\n\t"
       "s_mov_b64 exec, %[sp]\n\t"                         // left the parent: POP
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
@@ -287,12 +304,12 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       SVO_POP_ADDR
       "ds_read_b32 %[self], %[t0]\n\t"                    // a level this ray never pushed holds the zeros it started on:
       "ds_read_b32 %[tmax], %[t0] offset:4\n\t"           // state (0, 0) = descriptor 0, t_max 0
-      "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
+      "v_lshlrev_b32_e64 %[t3], %[scale], -4\n\t"       // ~0 << scale
       "v_mov_b32 %[h], 0\n\t"                             // h = 0
       "v_and_b32 %[px], %[px], %[t3]\n\t"                 // round the position to the cell
       "v_and_b32 v56, v56, %[t3]\n\t"
       "v_and_b32 v57, v57, %[t3]\n\t"
-      "v_cmp_le_u32 vcc, 23, %[scale]\n\t"                // left the octree: MISS
+      "v_cmp_le_u32 vcc, 21, %[scale]\n\t"                // left the octree (scale 23): MISS
       "s_waitcnt lgkmcnt(0)\n\t"
       "s_cmp_lg_u64 vcc, 0\n\t"
       "s_cbranch_scc1 Lmiss%=\n"                          // out of line
@@ -333,7 +350,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
 #endif
       : [cx] "v"(r.cx), [bx] "v"(r.bx),
         [cy] "v"(r.cyz.x), [cz] "v"(r.cyz.y), [by] "v"(r.byz.x), [bz] "v"(r.byz.y), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
-        [lds8] "v"(lds8), [ldsb] "v"(ldsb), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u), [thresh] "s"(threshold)
+        [lds8] "v"(lds8), [ldsb] "v"(ldsb), [rsd] "s"(tab.rsrc), [kexp] "s"(0x35000000u), [thresh] "s"(threshold)
 #ifdef SVO_STAMPS
         , [lane] "v"(lane)
 #endif

@@ -174,10 +174,12 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
       "v_cmp_le_f32_e64 %[sg], v60, %[tcm]\n\t"
       "v_cmp_le_f32_e64 %[sh], v61, %[tcm]\n\t"
       "s_waitcnt vmcnt(0)\n\t"
-      "v_lshrrev_b32 %[bit], %[cs], v65\n\t"            // bit cs of the ne byte -> bit 0, of the has byte -> bit 8
-      "v_and_b32 %[bit], %[k101], %[bit]\n\t"
-      "v_cmp_ne_u32_sdwa %[sa], %[bit], %[zero] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   // child not empty
-      "v_cmp_ne_u32_sdwa vcc, %[bit], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"     // child has a child block
+      // (this loop keeps scale and child slot unbiased, unlike trav_loop2: one shift more per trip)
+      "v_lshlrev_b32_e64 %[bit], 2, %[cs]\n\t"
+      "v_lshrrev_b32 %[bit], %[bit], v65\n\t"          // the child's nibble: 0 empty, 1 not empty, 8 | rank with a child block
+      "v_and_b32 %[bit], 15, %[bit]\n\t"
+      "v_cmp_ne_u32_e64 %[sa], 0, %[bit]\n\t"           // child not empty
+      "v_cmp_lt_u32 vcc, 7, %[bit]\n\t"                 // child has a child block
       // lane sets
       "s_and_b64 %[sd], %[sd], vcc\n\t"
       "s_and_b64 %[sd], %[sd], %[sa]\n\t"                 // DESCEND = not empty & in range & !at LOD & inside & child block
@@ -192,13 +194,11 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
       SVO_COUNT("c2", "c3", "exec")
       "v_cmp_lt_f32 vcc, %[tcm], %[h]\n\t"                // tc_max < h: PUSH
       "v_mul_f32 v58, 0.5, v58\n\t"                       // half
-      SVO_PUSH_ADDR
+      "s_and_saveexec_b64 %[sb], vcc\n\t"
+      "v_lshl_add_u32 v63, %[scale], 9, %[ldsb]\n\t"
       "ds_write2_b32 v63, %[self], %[tmax] offset1:1\n\t" // {parent state, t_max}
       "s_mov_b64 exec, %[sd]\n\t"
-      "v_bfm_b32 %[t1], %[cs], 8\n\t"                     // the has bits of the children below cs
-      "v_and_b32 %[t1], %[t1], v65\n\t"
-      "v_bcnt_u32_b32 %[t1], %[t1], 0\n\t"
-      "v_lshl_add_u32 %[self], %[t1], 3, v64\n\t"         // the child's descriptor
+      "v_lshl_add_u32 %[self], %[bit], 3, v64\n\t"        // the child's descriptor: (first - 64) + 8 * (8 | rank)
       "v_mul_f32 %[t0], %[cx], v58\n\t"
       "v_mul_f32 v62, %[cy], v58\n\t"
       "v_mul_f32 v63, %[cz], v58\n\t"
@@ -244,7 +244,9 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
       SVO_COUNT("c6", "c7", "exec")
       // ---- POP (svotrace.comp:341-366)
       "v_ffbh_u32 %[t0], %[t0]\n\t"                       // (the differing bits of a POP lane are never zero: d >> scale > 1)
-      SVO_POP_ADDR
+      "v_xor_b32 %[scale], 31, %[t0]\n\t"
+      "v_lshl_add_u32 v58, %[scale], 23, %[kexp]\n\t"
+      "v_lshl_add_u32 %[t0], %[scale], 9, %[ldsb]\n\t"
       "ds_read_b32 %[self], %[t0]\n\t"                    // a level this ray never pushed holds the zeros it started on:
       "ds_read_b32 %[tmax], %[t0] offset:4\n\t"           // state (0, 0) = descriptor 0, t_max 0
       "v_lshlrev_b32_e64 %[t3], %[scale], -1\n\t"
@@ -365,7 +367,7 @@ __device__ __forceinline__ void trav_loop3(const DescTab &tab, WaveStack2 &stk, 
 #ifdef SVO_STAMPS
         , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7), [hist] "+v"(hist)
 #endif
-      : [k005] "s"(0.05f), [lds8] "v"(lds8), [ldsb] "v"(ldsb), [rsd] "s"(tab.rsrc), [k101] "s"(0x101u), [zero] "s"(0u), [kexp] "s"(0x34000000u),
+      : [k005] "s"(0.05f), [lds8] "v"(lds8), [ldsb] "v"(ldsb), [rsd] "s"(tab.rsrc), [kexp] "s"(0x34000000u),
         [thresh] "s"(threshold), [rootlo] "s"(rootd.x), [roothi] "s"(rootd.y), [bias] "s"(kIterBias), [kone] "s"(0x3f800000u)
 #ifdef SVO_STAMPS
         , [lane] "v"(lane)
