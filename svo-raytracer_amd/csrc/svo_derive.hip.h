@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include "svo_build.hip.h"
 #include "svo_trav.h"
+#include "svo_descword.h"
 
 namespace svo {
 namespace derive {
@@ -41,24 +42,6 @@ namespace derive {
 constexpr uint32_t kPhantom = 0u, kRoot = 1u;
 constexpr int kLevels = kMaxDepth;   // parent states at depth 0..12
 constexpr size_t kHeadroom = 1u << 16;
-constexpr uint32_t kGroupBias = 64u;   // desc.x = 8 * (index of the first child descriptor) - 64: + 8 * (8 | rank) is the child's
-
-// the second word of a descriptor from the masks of its children (has is a subset of ne), and back
-__host__ __device__ inline uint32_t desc_word(uint32_t m_ne, uint32_t m_has) {
-  uint32_t w = 0, rank = 0;
-  for (uint32_t c = 0; c < 8; c++) {
-    if ((m_has >> c) & 1u) w |= (8u | rank++) << (4u * c);
-    else if ((m_ne >> c) & 1u) w |= 1u << (4u * c);
-  }
-  return w;
-}
-__host__ __device__ inline uint32_t desc_has(uint32_t w) {
-  uint32_t m = 0;
-  for (uint32_t c = 0; c < 8; c++) m |= ((w >> (4u * c + 3u)) & 1u) << c;
-  return m;
-}
-__host__ __device__ inline uint32_t desc_first(uint32_t x) { return (x + kGroupBias) >> 3; }   // index of the first child descriptor
-__host__ __device__ inline uint32_t desc_base(uint32_t first) { return first * 8u - kGroupBias; }
 
 struct Table {
   uint2 *desc = nullptr;
