@@ -18,9 +18,9 @@ for wpc in (8, 10, 14, 20):
     for frame in (2, 3):
         ctx.set_params(frame, 0, 0, 0, 2, 0, 1)
         ms = ctx.time_frames(2, 1)
-        buf = np.zeros(32, dtype=np.uint32)
+        buf = np.zeros(96, dtype=np.uint32)   # 16 x u64 of diagnostics + the 64-word histogram (svo_debug_heads: 384 bytes)
         L.svo_debug_heads(ctx._h, buf.ctypes.data)
-        d = [int(x) for x in buf.view(np.uint64)]
+        d = [int(x) for x in buf[:32].view(np.uint64)]
         nw = 256 * wpc
         begin = M - d[6]
         first_dry = M - d[7]
