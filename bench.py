@@ -283,7 +283,7 @@ def launch_ranks(args, argv=None, runner=run_rung):
     return 1
 
 
-KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop2.h", "svo_trav2.h", "svo_derive.hip.h", "svo_travloop.h", "svo_trav.h",
+KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop2.h", "svo_trav2.h", "svo_derive.hip.h", "svo_descword.h", "svo_travloop.h", "svo_trav.h",
                   "svo_device.h", "svo_fused.hip.h", "svo_kernels.h", "Makefile")
 
 

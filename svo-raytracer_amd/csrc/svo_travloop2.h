@@ -3,12 +3,12 @@
 // trav_loop2() runs trav_step2() (svo_trav2.h) on the wave's active lanes until no more than `threshold` of them are
 // still traversing.  Against the byte walk's loop (svo_travloop.h) a trip loses: the child-offset arithmetic (two
 // shifts, a bit-op, an and, three popcounts, two mads: it is only needed for the hit pointer, once per cast, after the
-// loop), the two record loads of EVERY trip (the child's "empty" and "has a child block" bits come from the parent's
-// descriptor: a shift, an and and two v_cmp on a register), the cp / tag-mask extraction, the 16-bit tag-mask plane of
+// loop), the two record loads of EVERY trip (whether the child is empty and whether it has a child block is a nibble of
+// the parent's descriptor: one v_bfe and two v_cmp on a register), the cp / tag-mask extraction, the 16-bit tag-mask plane of
 // the stack and the pushed-levels mask (a PUSH is one ds_write2_b32 of {descriptor offset, t_max}; a POP two ds_read_b32
 // straight into the state registers: the caller zeroes a lane's stack column when it sets up a ray, so a level the ray
-// never pushed reads as the reference's zero-initialised entry).  What it gains is the rank of the child among the
-// parent's children with a child block (v_bfm, v_and, v_bcnt, v_lshl_add).
+// never pushed reads as the reference's zero-initialised entry).  What it gains is one shift-add: the child's descriptor offset from
+// that nibble (v_lshl_add_u32; until round 5's nibbles the rank among the parent's `has` bits: v_bfm, v_and, v_bcnt, v_lshl_add).
 //   trips load only for lanes that DESCEND or POP: one aligned 8-byte descriptor (49 cycles of the texture path per
 //   wave-level load against 2 x 34 for the two unaligned dwords of a record, tools/calib_td.hip), issued at the end
 //   of the trip for both lane sets together, waited for at the top of the next trip behind everything that does not
