@@ -195,8 +195,9 @@ int svo_set_sequence(svo_ctx *ctx, int nframes, int fresh);
 int svo_set_batch(svo_ctx *ctx, int nframes, uint64_t frame_stride);
 /* The interior-descriptor table: a derived acceleration copy of the pool inside the library ("a derived
  * acceleration copy inside the library is allowed, results must not change").  The shader fetches a child record in
- * every iteration only to learn "empty?" (svotrace.comp:295) and "leaf?" (:311); the table keeps those two bits of all
- * eight children in an 8-byte descriptor of the PARENT, so that only a descend loads (one aligned descriptor) and the
+ * every iteration only to learn "empty?" (svotrace.comp:295) and "leaf?" (:311); the table keeps those two answers for all
+ * eight children (a nibble each: empty / leaf / "descend, into the n-th child descriptor") in an 8-byte descriptor of the
+ * PARENT, so that only a descend loads (one aligned descriptor) and the
  * pool's records are read once per cast, for the node it ends on.  Built on the GPU at the first dispatch after a pool
  * change (svo_pool_upload / _update / builders), walked by pipeline 1.  mode 1 (default): use it when the pool can be
  * derived (up to 13 levels, unrolling within budget -- anything a builder produces); otherwise, and with mode 0, the
