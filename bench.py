@@ -94,7 +94,16 @@ def parse(argv=None):
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel accumulated per frame (svotrace.comp:668-670)")
     ap.add_argument("--seq", type=int, default=None, help="frames of the cross-frame accumulation (svotrace.comp:712-719) per step: "
                                                           "one step = frameNumber 2 .. seq + 1 blended into one image (svo_set_sequence)")
-    ap.add_argument("--camera", default="K1")
+    ap.add_argument("--camera", default="K1", help="K0 (the reference's default, Main.java:120), K1, K2 (grazing): SURVEY 8(d)")
+    ap.add_argument("--scene", choices=["terrain", "caves"], default="terrain",
+                    help="scene family: terrain = the integer-noise height field (SURVEY 8d), built on the GPU from its two maps; caves = "
+                         "the same terrain under levels of hashed balls that carve it or float over it (overhangs, cave mouths, boulders, "
+                         "floating debris: scene/svo_scene.c family 1), built on the host cores and uploaded")
+    ap.add_argument("--seed", type=int, default=1, help="seed of the scene's integer noise")
+    ap.add_argument("--amp", type=int, default=8, help="terrain amplitude in sixteenths of an octave's cell (8 = the default terrain)")
+    ap.add_argument("--dens", type=int, default=None, help="caves: probability / 256 that a cell next to a surface holds a ball (default 64)")
+    ap.add_argument("--by-camera", type=int, default=1, help="also measure the default configuration from each of SURVEY 8(d)'s cameras "
+                                                             "K0 / K1 / K2, 100 verified steps each (value_by_camera; one GPU, C3 only)")
     ap.add_argument("--camera-path", choices=["static", "orbit"], default="static",
                     help="orbit: every timed frame carries its own camera (Camera.rotate + strafe through the host mirror) and "
                          "frameNumber 1 (Main resets it on motion, Main.java:225-233, 275): svo_ring_submit_cams")
@@ -319,6 +328,12 @@ def pmc_key(args, width, height, nbuf, batch):
         key += "_beam"
     if args.camera != "K1":
         key += "_" + args.camera
+    if args.scene != "terrain":
+        key += "_" + args.scene + ("_d%d" % args.dens if args.dens is not None else "")
+    if args.seed != 1:
+        key += "_seed%d" % args.seed
+    if args.amp != 8:
+        key += "_amp%d" % args.amp
     if args.mirror:
         key += "_mirror%x" % args.mirror
     return key
@@ -590,8 +605,23 @@ def main(argv=None, ctx_factory=None):
     # svo_build_from_heightmap), replicated by one RCCL broadcast ------------------------------------------
     t_build = time.time()
     pool = None
-    if rank == 0:
-        hmap, mmap = scene.scene_maps(args.size)
+    if rank == 0 and args.scene == "caves":
+        # family 1 has no height map to build from: the host cores make the pool, svo_pool_upload copies it (Renderer.addSSBO)
+        dens = scene.CAVES_DENS if args.dens is None else args.dens
+        # (tools/matrix.py runs several cells on one scene: SVO_SCENE_CACHE = a directory that keeps the pool between runs)
+        cached = os.environ.get("SVO_SCENE_CACHE") and os.path.join(os.environ["SVO_SCENE_CACHE"],
+                                                                    "caves_%d_s%d_a%d_d%d.npy" % (args.size, args.seed, args.amp, dens))
+        if cached and os.path.exists(cached):
+            pool = np.load(cached)
+        else:
+            pool, _ = scene.build_scene3(args.size, args.seed, args.amp, dens)
+            if cached:
+                np.save(cached, pool)
+        nbytes = int(pool.size)
+        ctx.pool_upload(pool)
+        t_build = time.time() - t_build
+    elif rank == 0:
+        hmap, mmap = scene.scene_maps(args.size, args.seed, args.amp)
         nbytes = ctx.build_from_heightmap(hmap, mmap)
         t_build = time.time() - t_build
         del hmap, mmap
@@ -734,7 +764,7 @@ def main(argv=None, ctx_factory=None):
     # ---- the frames the ring still holds: the last nbuf timed frames, rendered with nbuf launches in flight ----
     ring.drain()
 
-    def verify_ring(first_ok):
+    def verify_ring(first_ok, vcam=None):
         """Every dispatch the ring still holds (its first and its last frame), a pixel subsample of each, bit for bit against
         the CPU oracle -- with the frame's own camera on a camera path, and through the oracle's statement of the cross-frame
         accumulation (svotrace.comp:712-719) for progressive sequences.  Returns (ok, description)."""
@@ -749,7 +779,7 @@ def main(argv=None, ctx_factory=None):
         for b, k in held:
             imgs = ring.frame_images(b, k)
             fr = imgs[0]
-            fcam = ring.cams_of[b][k] if ring.cams_of[b] is not None else cam
+            fcam = ring.cams_of[b][k] if ring.cams_of[b] is not None else (cam if vcam is None else vcam)
             col = imgs[1].cpu().numpy().view(np.uint8).reshape(H_total, W, 4)
             dep = imgs[2].cpu().numpy()
             ys = np.flatnonzero(rows_ok)[::step]      # every step-th row of those this run rendered
@@ -817,6 +847,36 @@ def main(argv=None, ctx_factory=None):
                 ring.drain()
             except Exception:
                 pass
+
+    # ---- the same configuration from each of SURVEY 8(d)'s three cameras: K0 = the reference's default (Main.java:120,
+    # Camera.java:13-18), K1 = inside the cube, pitched toward the terrain, K2 = grazing.  100 steps each, same ring, same
+    # protocol, the frames the region left in the ring verified against the oracle with that camera.
+    by_camera = None
+    if (args.by_camera and path is None and args.seq == 1 and world == 1 and not group_mode and as_rank is None and not stub
+            and args.pipeline == 1 and args.spp == 1 and (args.config or "C3") == "C3"):
+        by_camera = {}
+        for cname in ("K0", "K1", "K2"):
+            try:
+                ring.drain()
+                ctx.set_camera(CAMERAS[cname])
+                f0 = ring.first_frame + ring.k
+                csteps = 100
+                crays = float(np.mean([count(f0 + 2 * batch * nbuf + i)["rays"] for i in (0, csteps // 2, csteps - 1)]))
+                run_frames(2 * batch * nbuf)
+                cel = timed(csteps)
+                ring.drain()
+                cok, cinfo = verify_ring(f0 + 2 * batch * nbuf, vcam=CAMERAS[cname]) if args.verify else (None, None)
+                by_camera[cname] = {"value": round(crays * csteps / cel / 1e6, 2), "ms_per_step": round(cel / csteps * 1e3, 4),
+                                    "rays_per_frame": int(crays), "steps": csteps, "verified": cok, "verification": cinfo}
+                if args.verify and not cok:
+                    verified = False
+            except Exception as e:     # noqa: BLE001  (a leg behind the headline: reported, never loses the line)
+                by_camera[cname] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            ring.drain()
+            ctx.set_camera(cam)
+        except Exception:
+            pass
 
     # ---- the same configuration as a drop-in host drives it: JNI-typed calls only (what HipRenderer.java's natives are), a
     # context of its own, NO tuning / pipeline / hit-record call -- createFrameRing(6, 4), submitFrames, awaitFrames
@@ -920,6 +980,9 @@ def main(argv=None, ctx_factory=None):
             # the same configuration through JNI-typed calls only, no tuning / pipeline call: what a drop-in host gets by default
             "value_default_abi": default_abi["value"] if default_abi else None,
             "default_abi": default_abi,
+            # the default configuration from each of SURVEY 8(d)'s cameras (100 verified steps each; None where not measured)
+            "value_by_camera": ({k: v.get("value") for k, v in by_camera.items()} if by_camera else None),
+            "by_camera": by_camera,
             # the same protocol over a longer region (a 20-step region is 11 ms at N = 1, ~1.5 ms of work per rank at N = 8)
             "value_long_run": (round(rays * long_run[0] / long_run[1] / 1e6, 2) if long_run else None),
             "long_run_steps": (long_run[0] if long_run else None),
@@ -929,9 +992,12 @@ def main(argv=None, ctx_factory=None):
             "gather_ms": ring.gather_ms(),
             "comm_cus_per_xcd": comm_cus, "exchange": (args.exchange if ngpu > 1 else None), "fallback_from": negotiated,
             "config": {
-                "workload": "%s: %d^3 procedural terrain SVO (seed 1, %d bytes), %dx%d, renderMode %d (%s), %s, camera %s, "
+                "workload": "%s: %d^3 procedural %s SVO (seed %d, amplitude %d/16, %d bytes), %dx%d, renderMode %d (%s), %s, camera %s, "
                             "%s, pipeline %d, %s" % (
-                                args.config or "C3", args.size, nbytes, W, H_total, args.mode,
+                                args.config or "C3", args.size,
+                                "terrain" if args.scene == "terrain" else "caves (terrain + %d/256 hashed balls: overhangs, cave mouths, debris)" % (
+                                    scene.CAVES_DENS if args.dens is None else args.dens),
+                                args.seed, args.amp, nbytes, W, H_total, args.mode,
                                 ("primary + %d bounce(s)%s" % (args.bounces - 1, ", mirror mask 0x%x" % args.mirror if args.mirror else ""))
                                 if args.mode == 0 else ("primary + shadow ray" if args.mode == 2 else "primary only"),
                                 ("%d spp" % args.spp) if args.seq == 1 else

@@ -225,6 +225,22 @@ int svo_dispatch(svo_ctx *ctx);
  * svo_read_* waits for that stream first, every pool mutator for the whole device.  What Renderer.dispatchCompute of the
  * host mirrors (HipRenderer.java, host/svo_host.hpp) calls. */
 int svo_dispatch_async(svo_ctx *ctx);
+/* The reference's loop needs ONE pixel of frame N before it dispatches frame N + 1 (Main.updateEarly: the crosshair depth,
+ * Main.java:132-146 -- there a glGetTexImage of the whole 8.3 MB depth image that waits for the frame; SURVEY T11 "where the
+ * time goes today").  Here the two do not wait for each other:
+ *   - svo_dispatch_async alternates TWO sets {stream, colour / depth / hit images} while the library owns both (no
+ *     svo_set_stream / svo_bind_outputs, pipeline 1, no cross-frame accumulation, no batch): frame N + 1's persistent waves take
+ *     the CUs frame N's tail frees.  svo_read_color / _depth / _hits / _pixel and svo_output_device_ptrs always name the LAST
+ *     dispatched frame (GL's semantics: a read-back sees the last dispatch) and wait for it alone; svo_sync waits for both.
+ *     svo_set_overlap(ctx, 0) turns the alternation off (one stream, one image set, as before round 6).
+ *   - the pick pixel -- svo_set_pick(x, y); default the image centre, Main.java:139-141 -- is answered without waiting for its
+ *     frame: its 8x8 tile is the first its screen band draws, and the lane that stores the pixel also writes {rgba8, depth, hit
+ *     record} and the dispatch's sequence number to pinned host memory; svo_read_pixel at that position polls the word (no
+ *     stream synchronisation, no copy).  Any other position, a frame that carried no pick (other pipelines, stripes / row bands,
+ *     batches, accumulation, caller-owned outputs) or a negative x (= no pick) take the waiting path: same values either way
+ *     (tests/test_gpu_pick.py). */
+int svo_set_pick(svo_ctx *ctx, int x, int y);
+int svo_set_overlap(svo_ctx *ctx, int enabled);
 int svo_sync(svo_ctx *ctx);
 /* run the frame once more with counters on and fill svo_stats (untimed diagnostic pass) */
 int svo_count_frame(svo_ctx *ctx, svo_stats *out);

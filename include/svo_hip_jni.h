@@ -71,6 +71,8 @@ jint Java_src_engine_HipRenderer_nSetProgressive(void *env, void *cls, jlong ctx
 /* ---- the rest of the C ABI's dispatch surface (include/svo_hip.h), same LWJGL style ---- */
 jint Java_src_engine_HipRenderer_nDispatchAsync(void *env, void *cls, jlong ctx);
 jint Java_src_engine_HipRenderer_nSync(void *env, void *cls, jlong ctx);
+jint Java_src_engine_HipRenderer_nSetPick(void *env, void *cls, jlong ctx, jint x, jint y);       /* svo_set_pick */
+jint Java_src_engine_HipRenderer_nSetOverlap(void *env, void *cls, jlong ctx, jint enabled);     /* svo_set_overlap */
 /* hipStream_t as a long; 0 = the library's own stream */
 jint Java_src_engine_HipRenderer_nSetStream(void *env, void *cls, jlong ctx, jlong hip_stream);
 jint Java_src_engine_HipRenderer_nSetPipeline(void *env, void *cls, jlong ctx, jint pipeline);

@@ -342,6 +342,23 @@ public class HipRenderer {
     check(nSync(ctx));
   }
 
+  /**
+   * svo_set_pick: the pixel readDepthPixel answers without waiting for its frame (default: the image centre, the crosshair of
+   * Main.java:139-141).  The frame's pick tile is drawn first and its lane writes the value to pinned host memory; a negative x
+   * switches the pick off (every read-back then waits for the frame).
+   */
+  public void setPick(int x, int y) {
+    check(nSetPick(ctx, x, y));
+  }
+
+  /**
+   * svo_set_overlap: dispatchCompute alternates two {stream, image} sets so that frame N + 1 starts in frame N's tail (default
+   * on); read-backs always see the last dispatched frame.  false = one stream, one image set.
+   */
+  public void setOverlap(boolean enabled) {
+    check(nSetOverlap(ctx, enabled ? 1 : 0));
+  }
+
   /** svo_set_stream: a caller-owned hipStream_t (0 = the library's own). */
   public void setStream(long hipStream) {
     check(nSetStream(ctx, hipStream));
@@ -597,6 +614,8 @@ public class HipRenderer {
   private static native int nReadPixel(long ctx, int x, int y, long rgbaAddr, long depthAddr, long hitAddr);
   private static native int nDispatchAsync(long ctx);
   private static native int nSync(long ctx);
+  private static native int nSetPick(long ctx, int x, int y);
+  private static native int nSetOverlap(long ctx, int enabled);
   private static native int nSetStream(long ctx, long hipStream);
   private static native int nSetPipeline(long ctx, int pipeline);
   private static native int nSetTuning(long ctx, int wavesPerCu, int roundThresholdSixteenths);

@@ -57,6 +57,23 @@ struct svo_ctx {
   uint32_t *own_color = nullptr;
   float *own_depth = nullptr;
   uint4 *own_hits = nullptr;
+  // svo_dispatch_async alternates two sets {stream, images} while the library owns both (the reference's loop, Main.java:132-146,
+  // 257-289: frame N + 1 starts in frame N's tail): set 0 = own_stream + own_*, set 1 = alt_stream + alt_* (made on first use).
+  // c->stream / c->d_* always name ONE set, the one of the last dispatch, so every read-back sees the last dispatched frame.
+  hipStream_t alt_stream = nullptr;
+  uint32_t *alt_color = nullptr;
+  float *alt_depth = nullptr;
+  uint4 *alt_hits = nullptr;
+  int cur_set = 0;
+  int overlap = 1;             // svo_set_overlap
+  bool alt_inflight = false;   // the set that is not current may still have a frame in flight
+  // the pick pixel (svo_set_pick): answered from pinned host memory by the lane that stores it
+  int pick_x = -1, pick_y = -1;
+  bool pick_default = true;    // follows the image centre (the crosshair, Main.java:139-141) until svo_set_pick names a pixel
+  uint32_t *pick_mail = nullptr;   // kPickSlots x kPickWords words of host memory the device writes
+  uint32_t pick_seq = 0;       // sequence number of the last dispatch that carried the pick
+  bool pick_live = false;      // the current set's last dispatch carried it (cleared by everything else that renders into the set)
+  int pick_live_x = -1, pick_live_y = -1;
   DeviceCounters *d_counters = nullptr;
   float4 *d_ntab = nullptr;   // unit normal of every 16-bit normal code (svo_trav2.h::normal_table_kernel), made with the context
   // beam images: one per frame in flight, re-used round-robin behind the event of the frame that read it last
@@ -173,6 +190,12 @@ static void free_outputs(svo_ctx *c) {
   if (c->own_depth) (void)hipFree(c->own_depth);
   if (c->own_hits) (void)hipFree(c->own_hits);
   c->own_color = nullptr; c->own_depth = nullptr; c->own_hits = nullptr;
+  if (c->alt_color) (void)hipFree(c->alt_color);
+  if (c->alt_depth) (void)hipFree(c->alt_depth);
+  if (c->alt_hits) (void)hipFree(c->alt_hits);
+  c->alt_color = nullptr; c->alt_depth = nullptr; c->alt_hits = nullptr;
+  if (c->cur_set == 1 && (c->stream == c->alt_stream || c->stream == nullptr)) c->stream = c->own_stream;
+  c->cur_set = 0; c->alt_inflight = false; c->pick_live = false;
   if (!c->external_outputs) { c->d_color = nullptr; c->d_depth = nullptr; c->d_hits = nullptr; }
   wavefront_free(c->wf);
   persist_free(c->pb);
@@ -200,6 +223,8 @@ int svo_destroy(svo_ctx *c) {
   ring_free(c);
   for (void *p : c->ipc_opened) if (p) (void)hipIpcCloseMemHandle(p);
   for (void *p : c->dev_allocs) if (p) (void)hipFree(p);
+  if (c->alt_stream) (void)hipStreamDestroy(c->alt_stream);
+  if (c->pick_mail) (void)hipHostFree(c->pick_mail);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return SVO_OK;
@@ -451,6 +476,8 @@ int svo_resize(svo_ctx *c, int width, int height) {
   HIPCHK(c, hipDeviceSynchronize());
   if (!c->external_outputs) { c->d_color = c->own_color; c->d_depth = c->own_depth; c->d_hits = c->own_hits; }
   c->width = width; c->height = height;
+  if (c->pick_default) { c->pick_x = width / 2; c->pick_y = height / 2; }   // the crosshair: Main.java:139-141 reads (WIDTH / 2, HEIGHT / 2)
+  else if (c->pick_x >= width || c->pick_y >= height) { c->pick_x = -1; c->pick_y = -1; }
   c->y0 = 0; c->y1 = height; c->rows_set = false;  // a new image size resets the row band to the whole frame
   c->row_step = 1; c->out_y0 = 0; c->n_tile_rows = -1;
   return SVO_OK;
@@ -458,9 +485,11 @@ int svo_resize(svo_ctx *c, int width, int height) {
 
 int svo_bind_outputs(svo_ctx *c, void *color, void *depth, void *hits) {
   if (!c) return SVO_E_INVALID;
+  c->pick_live = false;
   if (!color) {
     c->external_outputs = false;
-    c->d_color = c->own_color; c->d_depth = c->own_depth; c->d_hits = c->own_hits;
+    const bool alt = c->cur_set == 1 && c->alt_color;
+    c->d_color = alt ? c->alt_color : c->own_color; c->d_depth = alt ? c->alt_depth : c->own_depth; c->d_hits = alt ? c->alt_hits : c->own_hits;
     return SVO_OK;
   }
   if (!depth) return fail(c, SVO_E_INVALID, "svo_bind_outputs: depth buffer required");
@@ -574,7 +603,33 @@ int svo_set_stream(svo_ctx *c, void *hip_stream) {
   // no synchronisation here: a caller may alternate streams to keep two frames in flight
   // (different output buffers); ordering between streams is the caller's business.  The library's own stream lives as
   // long as the context: NULL returns to it.
-  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  if (hip_stream) {
+    // leaving the library's own streams: what they still have in flight writes the library's images, which dispatches on the
+    // caller's stream may render into next
+    if (c->alt_inflight || c->stream == c->own_stream || c->stream == c->alt_stream) {
+      HIPCHK(c, hipStreamSynchronize(c->own_stream));
+      if (c->alt_stream) HIPCHK(c, hipStreamSynchronize(c->alt_stream));
+      c->alt_inflight = false;
+    }
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    c->stream = (c->cur_set == 1 && c->alt_stream) ? c->alt_stream : c->own_stream;   // the current set's own
+  }
+  c->pick_live = false;
+  return SVO_OK;
+}
+
+int svo_set_overlap(svo_ctx *c, int enabled) {
+  if (!c) return SVO_E_INVALID;
+  c->overlap = enabled ? 1 : 0;
+  return SVO_OK;
+}
+
+int svo_set_pick(svo_ctx *c, int x, int y) {
+  if (!c) return SVO_E_INVALID;
+  if (x < 0 || y < 0) { c->pick_x = -1; c->pick_y = -1; c->pick_default = false; return SVO_OK; }   // no pick: read-backs wait
+  if (c->width > 0 && (x >= c->width || y >= c->height)) return fail(c, SVO_E_INVALID, "svo_set_pick: outside the image");
+  c->pick_x = x; c->pick_y = y; c->pick_default = false;
   return SVO_OK;
 }
 
@@ -779,16 +834,68 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
   return SVO_OK;
 }
 
+// the frame's pick request: a mail slot of its own per dispatch (kPickSlots of them, round-robin)
+static int arm_pick(svo_ctx *c) {
+  c->pb.pick = PickRequest();
+  c->pb.pick_carried = false;
+  c->pick_live = false;
+  if (c->pick_x < 0 || c->pipeline != 1 || c->batch != 1 || c->external_outputs) return SVO_OK;
+  if (!c->pick_mail) {
+    HIPCHK(c, hipHostMalloc((void **)&c->pick_mail, (size_t)kPickSlots * kPickWords * sizeof(uint32_t), hipHostMallocCoherent));
+    memset(c->pick_mail, 0, (size_t)kPickSlots * kPickWords * sizeof(uint32_t));
+  }
+  const uint32_t seq = c->pick_seq + 1u == 0u ? 1u : c->pick_seq + 1u;   // (0 = "nothing written yet")
+  c->pb.pick.mail = c->pick_mail + (size_t)(seq % (uint32_t)kPickSlots) * kPickWords;
+  c->pb.pick.x = c->pick_x; c->pb.pick.y = c->pick_y; c->pb.pick.seq = seq;
+  return SVO_OK;
+}
+static void pick_armed(svo_ctx *c, int rc) {
+  if (rc == SVO_OK && c->pb.pick.mail && c->pb.pick_carried) {
+    c->pick_seq = c->pb.pick.seq;
+    c->pick_live = true; c->pick_live_x = c->pb.pick.x; c->pick_live_y = c->pb.pick.y;
+  }
+  c->pb.pick = PickRequest();
+}
+
 int svo_dispatch_async(svo_ctx *c) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  return launch_frame(c, false);
+  // Two sets {stream, images} in turn while the library owns both and nothing ties a frame to the image before it: the next
+  // frame's persistent waves take the CUs this frame's tail frees (glDispatchCompute only enqueues as well: Renderer.java:118-121).
+  const bool own = !c->external_outputs && c->own_color && (c->stream == c->own_stream || (c->alt_stream && c->stream == c->alt_stream));
+  if (c->overlap && own && c->pipeline == 1 && !c->progressive && c->batch == 1) {
+    if (!c->alt_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking));
+    if (!c->alt_color) {
+      const size_t n = (size_t)c->width * (size_t)c->height;
+      HIPCHK(c, hipMalloc((void **)&c->alt_color, n * 4));
+      HIPCHK(c, hipMalloc((void **)&c->alt_depth, n * 4));
+      HIPCHK(c, hipMalloc((void **)&c->alt_hits, n * 16));
+      HIPCHK(c, hipMemsetAsync(c->alt_color, 0, n * 4, c->alt_stream));
+      HIPCHK(c, hipMemsetAsync(c->alt_depth, 0, n * 4, c->alt_stream));
+      HIPCHK(c, hipMemsetAsync(c->alt_hits, 0, n * 16, c->alt_stream));
+    }
+    c->cur_set ^= 1;
+    const bool alt = c->cur_set == 1;
+    c->stream = alt ? c->alt_stream : c->own_stream;
+    c->d_color = alt ? c->alt_color : c->own_color; c->d_depth = alt ? c->alt_depth : c->own_depth; c->d_hits = alt ? c->alt_hits : c->own_hits;
+    c->alt_inflight = true;
+  }
+  int rc = arm_pick(c);
+  if (rc) return rc;
+  rc = launch_frame(c, false);
+  pick_armed(c, rc);
+  return rc;
 }
 
 int svo_sync(svo_ctx *c) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->alt_inflight) {   // the other set's frame too
+    HIPCHK(c, hipStreamSynchronize(c->own_stream));
+    if (c->alt_stream) HIPCHK(c, hipStreamSynchronize(c->alt_stream));
+    c->alt_inflight = false;
+  }
   return SVO_OK;
 }
 
@@ -796,7 +903,10 @@ int svo_dispatch(svo_ctx *c) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  int rc = launch_frame(c, false);
+  int rc = arm_pick(c);
+  if (rc) return rc;
+  rc = launch_frame(c, false);
+  pick_armed(c, rc);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -809,6 +919,7 @@ int svo_dispatch(svo_ctx *c) {
 int svo_count_frame(svo_ctx *c, svo_stats *out) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  c->pick_live = false;   // (the counting pass renders into the current images)
   int rc = launch_frame(c, true);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -829,6 +940,7 @@ int svo_get_stats(svo_ctx *c, svo_stats *out) {
 int svo_time_frames(svo_ctx *c, int warmup, int iters, float *ms) {
   if (!c || iters <= 0 || !ms) return fail(c, SVO_E_INVALID, "svo_time_frames: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
+  c->pick_live = false;
   std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
   int rc = SVO_OK;
   hipError_t e = hipSuccess;
@@ -1241,6 +1353,29 @@ int svo_read_pixel(svo_ctx *c, int x, int y, void *rgba8, float *depth, svo_hit 
   if (x < 0 || y < 0 || x >= c->width || y >= c->height) return fail(c, SVO_E_INVALID, "svo_read_pixel: outside the image");
   if (!c->d_color) return fail(c, SVO_E_INVALID, "readback before svo_resize");
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->pick_live && x == c->pick_live_x && y == c->pick_live_y && c->pick_mail && (!hit || (c->write_hits && c->d_hits))) {
+    // the pick pixel of the last dispatch: the lane that stored it has written (or will write) the mail slot -- no wait for
+    // the frame, no copy.  Should the stream run dry without the word (it cannot on a whole frame), the waiting path answers.
+    volatile uint32_t *m = c->pick_mail + (size_t)(c->pick_seq % (uint32_t)kPickSlots) * kPickWords;
+    bool got = false;
+    for (unsigned spin = 0;; spin++) {
+      if (__atomic_load_n((const uint32_t *)m, __ATOMIC_ACQUIRE) == c->pick_seq) { got = true; break; }
+      if ((spin & 255u) == 255u) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) { got = __atomic_load_n((const uint32_t *)m, __ATOMIC_ACQUIRE) == c->pick_seq; break; }
+        if (q != hipErrorNotReady) return fail(c, SVO_E_HIP, std::string("svo_read_pixel: ") + hipGetErrorString(q));
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    if (got) {
+      if (rgba8) { const uint32_t v = m[1]; memcpy(rgba8, &v, 4); }
+      if (depth) { const uint32_t v = m[2]; memcpy(depth, &v, 4); }
+      if (hit) { uint32_t h[4] = {m[4], m[5], m[6], m[7]}; memcpy(hit, h, 16); }
+      return SVO_OK;
+    }
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t o = (size_t)y * (size_t)c->width + (size_t)x;
   if (rgba8) HIPCHK(c, hipMemcpy(rgba8, c->d_color + o, 4, hipMemcpyDeviceToHost));

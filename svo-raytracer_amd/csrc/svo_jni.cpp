@@ -83,6 +83,8 @@ jint Java_src_engine_HipRenderer_nSetProgressive(void *, void *, jlong ctx, jint
 #define CTX(x) ((svo_ctx *)(intptr_t)(x))
 jint Java_src_engine_HipRenderer_nDispatchAsync(void *, void *, jlong ctx) { return svo_dispatch_async(CTX(ctx)); }
 jint Java_src_engine_HipRenderer_nSync(void *, void *, jlong ctx) { return svo_sync(CTX(ctx)); }
+jint Java_src_engine_HipRenderer_nSetPick(void *, void *, jlong ctx, jint x, jint y) { return svo_set_pick(CTX(ctx), x, y); }
+jint Java_src_engine_HipRenderer_nSetOverlap(void *, void *, jlong ctx, jint enabled) { return svo_set_overlap(CTX(ctx), enabled); }
 jint Java_src_engine_HipRenderer_nSetStream(void *, void *, jlong ctx, jlong hip_stream) {
   return svo_set_stream(CTX(ctx), (void *)(intptr_t)hip_stream);
 }

@@ -114,6 +114,8 @@ def lib(path=None):
         L.svo_dispatch.argtypes = [vp]
         L.svo_dispatch_async.argtypes = [vp]
         L.svo_sync.argtypes = [vp]
+        L.svo_set_pick.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        L.svo_set_overlap.argtypes = [vp, ctypes.c_int]
         L.svo_count_frame.argtypes = [vp, ctypes.POINTER(Stats)]
         L.svo_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
         L.svo_set_stream.argtypes = [vp, vp]
@@ -546,6 +548,14 @@ class HipContext:
 
     def dispatch_async(self):
         self._chk(self._L.svo_dispatch_async(self._h))
+
+    def set_pick(self, x, y):
+        """the pixel read_pixel answers without waiting for its frame (default: the image centre); x < 0: none"""
+        self._chk(self._L.svo_set_pick(self._h, int(x), int(y)))
+
+    def set_overlap(self, on):
+        """dispatch_async alternates two {stream, image} sets (default on)"""
+        self._chk(self._L.svo_set_overlap(self._h, 1 if on else 0))
 
     def sync(self):
         self._chk(self._L.svo_sync(self._h))

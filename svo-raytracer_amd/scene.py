@@ -44,6 +44,13 @@ def lib():
         L.svo_pool_validate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SceneStats),
                                         ctypes.POINTER(ctypes.c_int)]
         L.svo_pool_validate.restype = ctypes.c_int
+        L.svo_scene_build3.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(u8p),
+                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(SceneStats)]
+        L.svo_scene_build3.restype = ctypes.c_int
+        L.svo_scene3_voxels.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.svo_scene3_voxels.restype = ctypes.c_int
+        L.svo_scene3_ball_counts.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.svo_scene3_ball_counts.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -62,6 +69,56 @@ def build_scene(n, seed=1, amp=8):
     finally:
         L.svo_scene_free(p)
     return pool, st.as_dict()
+
+
+# Scene families (bench.py --scene, SURVEY 8d "Synthetic scenes"): "terrain" = the height field alone (what rounds 1-5
+# measured), "caves" = the same terrain under levels of hashed balls that carve it or float over it (scene/svo_scene.c,
+# "family 1": craters and cave mouths under overhanging rims, boulders, arches, floating debris -- real 3-D structure,
+# the integer analogue of the Worley part of the reference's chunkgen.comp:228-233).
+CAVES_DENS = 64     # dens / 256 = probability that a cell next to a surface holds a ball: 2.04 GB at 8192^3 (limit 2^31)
+
+
+def build_scene3(n, seed=1, amp=8, dens=CAVES_DENS):
+    """Build an n^3 family-1 ("caves") SVO.  Returns (pool: np.uint8[len], stats dict)."""
+    L = lib()
+    p = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_uint64()
+    st = SceneStats()
+    rc = L.svo_scene_build3(int(n), int(seed), int(amp), int(dens), ctypes.byref(p), ctypes.byref(ln), ctypes.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"svo_scene_build3({n}) failed rc={rc} (3 = pool would exceed 2^31 bytes: {ln.value})")
+    try:
+        pool = np.ctypeslib.as_array(p, shape=(ln.value,)).copy()
+    finally:
+        L.svo_scene_free(p)
+    return pool, st.as_dict()
+
+
+def scene3_voxels(n, seed=1, amp=8, dens=CAVES_DENS):
+    """The dense voxels grid[z, y, x] of a family-1 scene (n <= 1024): what the brute-force builders start from."""
+    g = np.zeros((n, n, n), dtype=np.uint8)
+    rc = lib().svo_scene3_voxels(int(n), int(seed), int(amp), int(dens), g.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"svo_scene3_voxels({n}) failed rc={rc}")
+    return g
+
+
+def scene3_ball_counts(n, seed=1, amp=8, dens=CAVES_DENS):
+    """[[carving, solid] per level] of a family-1 scene"""
+    c = np.zeros((4, 2), dtype=np.uint64)
+    rc = lib().svo_scene3_ball_counts(int(n), int(seed), int(amp), int(dens), c.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"svo_scene3_ball_counts({n}) failed rc={rc}")
+    return [[int(a), int(b)] for a, b in c]
+
+
+def build(family, n, seed=1, amp=8, dens=CAVES_DENS):
+    """pool, stats of scene family "terrain" or "caves" """
+    if family == "terrain":
+        return build_scene(n, seed, amp)
+    if family == "caves":
+        return build_scene3(n, seed, amp, dens)
+    raise ValueError("scene family %r (terrain | caves)" % (family,))
 
 
 def scene_maps(n, seed=1, amp=8):

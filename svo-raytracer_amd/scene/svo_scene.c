@@ -55,12 +55,25 @@ typedef struct {
   size_t len, cap;
 } buf_t;
 
+/* family 1 ("caves"): levels of hashed balls over the terrain (below).  A level = a grid of cells of edge C; a cell
+   holds at most one ball, wholly inside the cell. */
+#define MAX_BALL_LEVELS 4
+typedef struct {
+  int C, G;         /* cell edge in voxels, cells per axis (N / C) */
+  uint8_t *val;     /* per cell: 0xff = no ball, 0 = the ball carves (air), 1..3 = the ball is solid, of that material */
+  uint16_t *cx, *cy, *cz, *r;
+  int nocc;         /* occupancy pyramid: occ[j][cell of edge C << j] = a ball is present somewhere inside */
+  uint8_t **occ;
+} ball_level_t;
+
 typedef struct {
   int N, chunk, nlev;
   uint32_t seed;
   uint16_t *h;     /* N*N heights, index z*N + x */
   uint16_t **pmin; /* pyramid: level l covers cells of size 8<<l */
   uint16_t **pmax;
+  int nball;       /* 0 = family 0, the height-field terrain alone */
+  ball_level_t ball[MAX_BALL_LEVELS];
 } scene_t;
 
 typedef struct {
@@ -129,11 +142,128 @@ int svo_scene_maps(int N, uint32_t seed, int amp_num, uint16_t *height, uint8_t 
 }
 static inline int H(const scene_t *s, int x, int z) { return s->h[(size_t)z * s->N + x]; }
 /* voxel rule of chunkgen-heightmap.comp:16-28 */
-static inline uint8_t voxel(const scene_t *s, int x, int y, int z) {
+static inline uint8_t terrain_voxel(const scene_t *s, int x, int y, int z) {
   int h = H(s, x, z);
   if (y > h) return 0;
   if (h - y <= 4) return band_material(s, x, z);
   return 1;
+}
+
+/* ---------------------------------------------------------------- family 1: balls over the terrain
+ *
+ * The reference's own 3-D generator (chunkgen.comp:228-233: Perlin + simplex + Worley noise, thresholded) makes
+ * caves and overhangs; its float noise cannot be bounded over a cube, so it cannot be built at 8192^3 without the
+ * dense grid.  This family keeps the Worley part -- "solid / empty within r of a hashed feature point" -- in
+ * integers, where a cube can be tested against a ball exactly:
+ *
+ *   state_-1 = the height-field terrain above;
+ *   level k = 0..: a grid of cells of edge C_k = N >> (2 + 2k) (while C_k >= 8, at most 4 levels).  A cell may hold
+ *   one ball (radius C/8 .. 3C/8, centre hashed so that the ball stays inside its cell).  The ball INVERTS what
+ *   it finds: if its centre is solid in state_(k-1) it carves (value 0: craters, cave mouths under overhanging
+ *   rims, holes through coarser balls), else it is solid, of a hashed material 1..3 (boulders, arches where it is
+ *   half embedded, floating debris, rubble inside coarser cavities).  It exists only next to a surface of
+ *   state_(k-1) -- one of six probes along the axes, at r from a solid centre (a carving ball must breach) or at
+ *   2 r from an empty one, differs from the centre -- and then with probability dens / 256;
+ *   state_k(v) = the ball's value if v is inside the level-k ball of its cell, else state_(k-1)(v).
+ *
+ * Every quantity is scale-free in N, as the terrain is. */
+
+static inline uint32_t cell_hash(uint32_t seed, int k, int ix, int iy, int iz, uint32_t salt) {
+  return mix32((uint32_t)ix * 0x9E3779B1U ^
+               mix32((uint32_t)iy * 0x85EBCA77U ^ mix32((uint32_t)iz * 0xC2B2AE3DU ^ mix32(seed * 0x27d4eb2fU + (uint32_t)k * 0x165667B1U + salt))));
+}
+
+static inline int in_ball(const ball_level_t *b, size_t ci, int x, int y, int z) {
+  int64_t dx = x - (int)b->cx[ci], dy = y - (int)b->cy[ci], dz = z - (int)b->cz[ci], r = b->r[ci];
+  return dx * dx + dy * dy + dz * dz <= r * r;
+}
+
+/* state_(upto-1): the terrain overridden by the balls of levels 0 .. upto-1, the finest one that contains the voxel
+   deciding.  Outside the world: air. */
+static inline uint8_t state_upto(const scene_t *s, int upto, int x, int y, int z) {
+  if ((unsigned)x >= (unsigned)s->N || (unsigned)y >= (unsigned)s->N || (unsigned)z >= (unsigned)s->N) return 0;
+  for (int k = upto - 1; k >= 0; k--) {
+    const ball_level_t *b = &s->ball[k];
+    size_t ci = ((size_t)(z / b->C) * b->G + (size_t)(y / b->C)) * b->G + (size_t)(x / b->C);
+    if (b->val[ci] != 0xff && in_ball(b, ci, x, y, z)) return b->val[ci];
+  }
+  return terrain_voxel(s, x, y, z);
+}
+
+static inline uint8_t voxel(const scene_t *s, int x, int y, int z) {
+  return s->nball ? state_upto(s, s->nball, x, y, z) : terrain_voxel(s, x, y, z);
+}
+
+static void free_balls(scene_t *s) {
+  for (int k = 0; k < s->nball; k++) {
+    ball_level_t *b = &s->ball[k];
+    free(b->val); free(b->cx); free(b->cy); free(b->cz); free(b->r);
+    if (b->occ) for (int j = 0; j < b->nocc; j++) free(b->occ[j]);
+    free(b->occ);
+  }
+  s->nball = 0;
+}
+
+/* fill the level tables, coarse to fine (a level's balls look at the state the coarser levels left) */
+static int make_balls(scene_t *s, int dens) {
+  int N = s->N;
+  for (int k = 0; k < MAX_BALL_LEVELS; k++) {
+    int C = N >> (2 + 2 * k);
+    if (C < 8) break;
+    ball_level_t *b = &s->ball[k];
+    memset(b, 0, sizeof *b);
+    b->C = C; b->G = N / C;
+    size_t n = (size_t)b->G * b->G * b->G;
+    b->val = (uint8_t *)malloc(n);
+    b->cx = (uint16_t *)malloc(n * 2); b->cy = (uint16_t *)malloc(n * 2);
+    b->cz = (uint16_t *)malloc(n * 2); b->r = (uint16_t *)malloc(n * 2);
+    if (!b->val || !b->cx || !b->cy || !b->cz || !b->r) { s->nball = k + 1; return 2; }
+    int G = b->G;
+#pragma omp parallel for schedule(static)
+    for (int iz = 0; iz < G; iz++)
+      for (int iy = 0; iy < G; iy++)
+        for (int ix = 0; ix < G; ix++) {
+          size_t ci = ((size_t)iz * G + iy) * G + ix;
+          uint32_t hr = cell_hash(s->seed, k, ix, iy, iz, 1), hc = cell_hash(s->seed, k, ix, iy, iz, 2);
+          uint32_t hp = cell_hash(s->seed, k, ix, iy, iz, 3);
+          int r = C / 8 + (int)(hr % (uint32_t)(C / 4 + 1));
+          int span = C - 2 * r; /* centre in [cell + r, cell + C - 1 - r] */
+          int cx = ix * C + r + (int)((hc & 0x3ff) * (uint32_t)span >> 10);
+          int cy = iy * C + r + (int)(((hc >> 10) & 0x3ff) * (uint32_t)span >> 10);
+          int cz = iz * C + r + (int)(((hc >> 20) & 0x3ff) * (uint32_t)span >> 10);
+          b->cx[ci] = (uint16_t)cx; b->cy[ci] = (uint16_t)cy; b->cz[ci] = (uint16_t)cz; b->r[ci] = (uint16_t)r;
+          b->val[ci] = 0xff;
+          if ((int)(hp & 0xff) >= dens) continue;
+          uint8_t sc = state_upto(s, k, cx, cy, cz);
+          int D = sc ? r : 2 * r, near = 0;
+          static const int ax[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+          for (int a = 0; a < 6 && !near; a++)
+            near = (state_upto(s, k, cx + D * ax[a][0], cy + D * ax[a][1], cz + D * ax[a][2]) != 0) != (sc != 0);
+          if (!near) continue;
+          b->val[ci] = sc ? 0 : (uint8_t)(1 + ((hp >> 8) % 3));
+        }
+    /* occupancy pyramid */
+    int nocc = 1;
+    while ((G >> (nocc - 1)) > 1) nocc++;
+    b->nocc = nocc;
+    b->occ = (uint8_t **)calloc((size_t)nocc, sizeof(uint8_t *));
+    b->occ[0] = (uint8_t *)malloc(n);
+    for (size_t i = 0; i < n; i++) b->occ[0][i] = b->val[i] != 0xff;
+    for (int j = 1; j < nocc; j++) {
+      int g = G >> j, g2 = g * 2;
+      b->occ[j] = (uint8_t *)malloc((size_t)g * g * g);
+      for (int z = 0; z < g; z++)
+        for (int y = 0; y < g; y++)
+          for (int x = 0; x < g; x++) {
+            uint8_t o = 0;
+            for (int d = 0; d < 8; d++)
+              o |= b->occ[j - 1][((size_t)(2 * z + (d >> 2)) * g2 + (2 * y + ((d >> 1) & 1))) * g2 + (2 * x + (d & 1))];
+            b->occ[j][((size_t)z * g + y) * g + x] = o;
+          }
+    }
+    s->nball = k + 1; /* the next level sees this one */
+  }
+  return 0;
 }
 
 /* ---------------------------------------------------------------- byte pool */
@@ -184,15 +314,135 @@ static void set_mask(uint8_t *d, size_t parent, uint16_t m) { /* u16 big-endian,
 
 /* ---------------------------------------------------------------- classification */
 
-enum { K_EMPTY = 0, K_SOLID = 1, K_MIXED = 2 };
+enum { K_EMPTY = 0, K_SOLID = 1, K_MIXED = 2, K_UNKNOWN = 3 };
 
 static inline int in_chunk(const scene_t *s, int g, int c) {
   int o = (c / s->chunk) * s->chunk;
   return g >= o && g < o + s->chunk;
 }
 
+/* ---- family 1: exact classification of a cube without its voxels ----
+   prove3() decides what can be decided from the height pyramids and the cube's relation to the balls (each test exact
+   in integers); what it cannot decide is resolved by recursion down to cubes of 4, which are enumerated.  The result is
+   what the reference's scan over the dense voxels gives (tests/test_scene3.py: against the brute force over the grid). */
+
+/* 0 = the cube [c, c + cs) shares no voxel with the ball, 1 = all its voxels are inside, 2 = some are */
+static inline int ball_relation(const ball_level_t *b, size_t ci, int cx, int cy, int cz, int cs) {
+  int c0[3] = {cx, cy, cz}, bc[3] = {b->cx[ci], b->cy[ci], b->cz[ci]};
+  int64_t r2 = (int64_t)b->r[ci] * b->r[ci], dn = 0, df = 0;
+  for (int a = 0; a < 3; a++) {
+    int lo = c0[a], hi = c0[a] + cs - 1;
+    int64_t near = bc[a] < lo ? lo - bc[a] : bc[a] > hi ? bc[a] - hi : 0;
+    int64_t far = (bc[a] - lo) > (hi - bc[a]) ? (bc[a] - lo) : (hi - bc[a]);
+    dn += near * near; df += far * far;
+  }
+  if (dn > r2) return 0;
+  return df <= r2 ? 1 : 2;
+}
+
+/* the terrain alone over a cube of 8 or more: exact (see classify() below for the argument) */
+static inline int terrain_kind(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *value) {
+  int l = 0;
+  while ((8 << l) < cs) l++;
+  int w = s->N / cs;
+  size_t pi = (size_t)(cz / cs) * w + (cx / cs);
+  int mn = s->pmin[l][pi], mx = s->pmax[l][pi];
+  if (mx < cy) { *value = 0; return K_EMPTY; }
+  if (cy + cs - 1 <= mn - 5) { *value = 1; return K_SOLID; }
+  *value = 0;
+  return K_MIXED;
+}
+
+static int prove3(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *value) {
+  uint8_t v;
+  int kind = terrain_kind(s, cx, cy, cz, cs, &v);
+  for (int k = 0; k < s->nball; k++) {
+    const ball_level_t *b = &s->ball[k];
+    if (cs > b->C) { /* the cube spans several cells of this (and of every finer) level: their balls lie wholly inside it */
+      int j = 0;
+      while ((b->C << j) < cs) j++;
+      int g = b->G >> j;
+      if (b->occ[j][((size_t)(cz / cs) * g + (size_t)(cy / cs)) * g + (size_t)(cx / cs)]) return K_UNKNOWN;
+      continue;
+    }
+    size_t ci = ((size_t)(cz / b->C) * b->G + (size_t)(cy / b->C)) * b->G + (size_t)(cx / b->C);
+    if (b->val[ci] == 0xff) continue;
+    int rel = ball_relation(b, ci, cx, cy, cz, cs);
+    if (rel == 0) continue;
+    if (rel == 1) { v = b->val[ci]; kind = v ? K_SOLID : K_EMPTY; continue; }
+    if ((kind == K_EMPTY || kind == K_SOLID) && v == b->val[ci]) continue; /* the ball changes nothing here */
+    kind = K_UNKNOWN;
+  }
+  *value = v;
+  return kind;
+}
+
+/* all voxels of the cube equal?  K_EMPTY / K_SOLID with the value, or K_MIXED */
+static int homog3(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *hv) {
+  if (cs < 8) {
+    uint8_t first = state_upto(s, s->nball, cx, cy, cz);
+    for (int z = cz; z < cz + cs; z++)
+      for (int y = cy; y < cy + cs; y++)
+        for (int x = cx; x < cx + cs; x++)
+          if (state_upto(s, s->nball, x, y, z) != first) return K_MIXED;
+    *hv = first;
+    return first ? K_SOLID : K_EMPTY;
+  }
+  int k = prove3(s, cx, cy, cz, cs, hv);
+  if (k != K_UNKNOWN) return k;
+  int h = cs / 2;
+  uint8_t v0 = 0;
+  for (int n = 0; n < 8; n++) {
+    uint8_t vn;
+    if (homog3(s, cx + (n & 1) * h, cy + ((n >> 1) & 1) * h, cz + ((n >> 2) & 1) * h, h, &vn) == K_MIXED) return K_MIXED;
+    if (n == 0) v0 = vn;
+    else if (vn != v0) return K_MIXED;
+  }
+  *hv = v0;
+  return v0 ? K_SOLID : K_EMPTY;
+}
+
+/* the first non-zero voxel of the cube in the reference's scan order (z outer, y, x inner; Octree.java:535-552):
+   smallest (z, y, x) -- *best is the smallest key found so far */
+static void first_nonzero3(const scene_t *s, int cx, int cy, int cz, int cs, uint64_t *best, uint8_t *bval) {
+  uint64_t lowkey = (uint64_t)cz << 32 | (uint64_t)cy << 16 | (uint64_t)cx;
+  if (lowkey >= *best) return; /* nothing in here comes earlier */
+  if (cs < 8) {
+    for (int z = cz; z < cz + cs; z++)
+      for (int y = cy; y < cy + cs; y++)
+        for (int x = cx; x < cx + cs; x++) {
+          uint8_t v = state_upto(s, s->nball, x, y, z);
+          if (!v) continue;
+          uint64_t key = (uint64_t)z << 32 | (uint64_t)y << 16 | (uint64_t)x;
+          if (key < *best) { *best = key; *bval = v; }
+          return; /* later voxels of this cube come later */
+        }
+    return;
+  }
+  uint8_t v;
+  int k = prove3(s, cx, cy, cz, cs, &v);
+  if (k == K_EMPTY) return;
+  v = state_upto(s, s->nball, cx, cy, cz);
+  if (v) { *best = lowkey; *bval = v; return; }
+  int h = cs / 2;
+  for (int n = 0; n < 8; n++)
+    first_nonzero3(s, cx + (n & 1) * h, cy + ((n >> 1) & 1) * h, cz + ((n >> 2) & 1) * h, h, best, bval);
+}
+
 /* classify region [cx,cx+cs) x [cy,cy+cs) x [cz,cz+cs); value per Octree.java:528-555 */
 static int classify(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *value) {
+  if (cs >= 8 && s->nball) {
+    uint8_t hv;
+    int k = homog3(s, cx, cy, cz, cs, &hv);
+    if (k != K_MIXED) { *value = hv; return k; }
+    uint8_t first = voxel(s, cx, cy, cz);
+    if (!first) {
+      uint64_t best = ~(uint64_t)0;
+      first_nonzero3(s, cx, cy, cz, cs, &best, &first);
+    }
+    *value = first;
+    return K_MIXED;
+  }
   if (cs >= 8) {
     int l = 0;
     while ((8 << l) < cs) l++;
@@ -242,7 +492,7 @@ static int surface_normal(const scene_t *s, int cx, int cy, int cz, uint16_t *pa
       int h = H(s, i, k);
       for (int j = cy - 1; j <= cy + 1; j++) {
         if (j < 0 || j >= s->N || !in_chunk(s, j, cy)) continue;
-        if (j > h) { exposed = 1; nx += i - cx; ny += j - cy; nz += k - cz; }
+        if (s->nball ? voxel(s, i, j, k) == 0 : j > h) { exposed = 1; nx += i - cx; ny += j - cy; nz += k - cz; }
       }
     }
   }
@@ -345,6 +595,7 @@ static void fill_top(buf_t *b, counts_t *cnt, size_t parent, int levels, int x, 
 }
 
 static void free_scene(scene_t *s) {
+  free_balls(s);
   if (s->pmin) for (int l = 0; l < s->nlev; l++) { free(s->pmin[l]); free(s->pmax[l]); }
   free(s->pmin); free(s->pmax); free(s->h);
 }
@@ -354,56 +605,55 @@ static void free_scene(scene_t *s) {
  * peak-to-peak amplitude in units of the octave's cell size (8 = default terrain).
  * Returns 0 on success; *out_pool is malloc'ed (free with svo_scene_free).
  */
+static int scene_setup(scene_t *s, int N, uint32_t seed, int amp_num, int dens);
+static int scene_build(int N, uint32_t seed, int amp_num, int dens, uint8_t **out_pool, uint64_t *out_len, svo_scene_stats *st);
+
 int svo_scene_build(int N, uint32_t seed, int amp_num, uint8_t **out_pool, uint64_t *out_len, svo_scene_stats *st) {
-  if (N < 8 || N > 8192 || (N & (N - 1))) return 1;
+  return scene_build(N, seed, amp_num, -1, out_pool, out_len, st);
+}
+
+/* family 1: the terrain with levels of hashed balls over it (caves, overhangs, boulders, floating debris; see "family 1"
+   above).  dens / 256 = the probability that a cell next to a surface holds a ball, 0 .. 256. */
+int svo_scene_build3(int N, uint32_t seed, int amp_num, int dens, uint8_t **out_pool, uint64_t *out_len, svo_scene_stats *st) {
+  if (dens < 0 || dens > 256) return 1;
+  return scene_build(N, seed, amp_num, dens, out_pool, out_len, st);
+}
+
+/* the dense voxels of a family-1 scene, grid[z][y][x] (tests: the brute-force builders start from these) */
+int svo_scene3_voxels(int N, uint32_t seed, int amp_num, int dens, uint8_t *grid) {
+  if (N < 8 || N > 1024 || (N & (N - 1)) || dens < 0 || dens > 256 || !grid) return 1;
   scene_t s;
-  memset(&s, 0, sizeof s);
-  s.N = N; s.seed = seed; s.chunk = N < CHUNK_SIZE ? N : CHUNK_SIZE;
-  s.h = (uint16_t *)malloc((size_t)N * N * sizeof(uint16_t));
-  if (!s.h) return 2;
+  int rc = scene_setup(&s, N, seed, amp_num, dens);
+  if (rc) { free_scene(&s); return rc; }
 #pragma omp parallel for schedule(static)
   for (int z = 0; z < N; z++)
-    for (int x = 0; x < N; x++) s.h[(size_t)z * N + x] = (uint16_t)svo_scene_height(N, seed, amp_num, x, z);
-  /* min/max pyramid, level l = cells of 8<<l */
-  int nlev = 0;
-  while ((8 << nlev) <= N) nlev++;
-  s.nlev = nlev;
-  s.pmin = (uint16_t **)calloc((size_t)nlev, sizeof(uint16_t *));
-  s.pmax = (uint16_t **)calloc((size_t)nlev, sizeof(uint16_t *));
-  for (int l = 0; l < nlev; l++) {
-    int cs = 8 << l, w = N / cs;
-    s.pmin[l] = (uint16_t *)malloc((size_t)w * w * 2);
-    s.pmax[l] = (uint16_t *)malloc((size_t)w * w * 2);
-    if (l == 0) {
-#pragma omp parallel for schedule(static)
-      for (int cz = 0; cz < w; cz++)
-        for (int cx = 0; cx < w; cx++) {
-          int mn = 65535, mx = 0;
-          for (int z = cz * 8; z < cz * 8 + 8; z++)
-            for (int x = cx * 8; x < cx * 8 + 8; x++) {
-              int h = s.h[(size_t)z * N + x];
-              if (h < mn) mn = h;
-              if (h > mx) mx = h;
-            }
-          s.pmin[0][(size_t)cz * w + cx] = (uint16_t)mn;
-          s.pmax[0][(size_t)cz * w + cx] = (uint16_t)mx;
-        }
-    } else {
-      int w2 = w * 2;
-      for (int cz = 0; cz < w; cz++)
-        for (int cx = 0; cx < w; cx++) {
-          int mn = 65535, mx = 0;
-          for (int dz = 0; dz < 2; dz++)
-            for (int dx = 0; dx < 2; dx++) {
-              size_t i = (size_t)(cz * 2 + dz) * w2 + (cx * 2 + dx);
-              if (s.pmin[l - 1][i] < mn) mn = s.pmin[l - 1][i];
-              if (s.pmax[l - 1][i] > mx) mx = s.pmax[l - 1][i];
-            }
-          s.pmin[l][(size_t)cz * w + cx] = (uint16_t)mn;
-          s.pmax[l][(size_t)cz * w + cx] = (uint16_t)mx;
-        }
+    for (int y = 0; y < N; y++)
+      for (int x = 0; x < N; x++) grid[((size_t)z * N + y) * N + x] = voxel(&s, x, y, z);
+  free_scene(&s);
+  return 0;
+}
+
+/* number of balls per level and kind (tests, bench line): out[level][0] = carving, out[level][1] = solid */
+int svo_scene3_ball_counts(int N, uint32_t seed, int amp_num, int dens, uint64_t out[MAX_BALL_LEVELS][2]) {
+  scene_t s;
+  int rc = scene_setup(&s, N, seed, amp_num, dens);
+  memset(out, 0, sizeof(uint64_t) * MAX_BALL_LEVELS * 2);
+  if (!rc)
+    for (int k = 0; k < s.nball; k++) {
+      size_t n = (size_t)s.ball[k].G * s.ball[k].G * s.ball[k].G;
+      for (size_t i = 0; i < n; i++)
+        if (s.ball[k].val[i] != 0xff) out[k][s.ball[k].val[i] != 0]++;
     }
-  }
+  free_scene(&s);
+  return rc;
+}
+
+static int scene_build(int N, uint32_t seed, int amp_num, int dens, uint8_t **out_pool, uint64_t *out_len, svo_scene_stats *st) {
+  if (N < 8 || N > 8192 || (N & (N - 1))) return 1;
+  scene_t s;
+  int rc0 = scene_setup(&s, N, seed, amp_num, dens);
+  if (rc0) { free_scene(&s); return rc0; }
+  int nlev = s.nlev;
 
   counts_t cnt;
   memset(&cnt, 0, sizeof cnt);
@@ -474,6 +724,59 @@ int svo_scene_build(int N, uint32_t seed, int amp_num, uint8_t **out_pool, uint6
   free_scene(&s);
   *out_pool = pool.d;
   *out_len = pool.len;
+  return 0;
+}
+
+static int scene_setup(scene_t *s, int N, uint32_t seed, int amp_num, int dens) {
+  memset(s, 0, sizeof *s);
+  s->N = N; s->seed = seed; s->chunk = N < CHUNK_SIZE ? N : CHUNK_SIZE;
+  s->h = (uint16_t *)malloc((size_t)N * N * sizeof(uint16_t));
+  if (!s->h) return 2;
+#pragma omp parallel for schedule(static)
+  for (int z = 0; z < N; z++)
+    for (int x = 0; x < N; x++) s->h[(size_t)z * N + x] = (uint16_t)svo_scene_height(N, seed, amp_num, x, z);
+  /* min/max pyramid, level l = cells of 8<<l */
+  int nlev = 0;
+  while ((8 << nlev) <= N) nlev++;
+  s->nlev = nlev;
+  s->pmin = (uint16_t **)calloc((size_t)nlev, sizeof(uint16_t *));
+  s->pmax = (uint16_t **)calloc((size_t)nlev, sizeof(uint16_t *));
+  for (int l = 0; l < nlev; l++) {
+    int cs = 8 << l, w = N / cs;
+    s->pmin[l] = (uint16_t *)malloc((size_t)w * w * 2);
+    s->pmax[l] = (uint16_t *)malloc((size_t)w * w * 2);
+    if (l == 0) {
+#pragma omp parallel for schedule(static)
+      for (int cz = 0; cz < w; cz++)
+        for (int cx = 0; cx < w; cx++) {
+          int mn = 65535, mx = 0;
+          for (int z = cz * 8; z < cz * 8 + 8; z++)
+            for (int x = cx * 8; x < cx * 8 + 8; x++) {
+              int h = s->h[(size_t)z * N + x];
+              if (h < mn) mn = h;
+              if (h > mx) mx = h;
+            }
+          s->pmin[0][(size_t)cz * w + cx] = (uint16_t)mn;
+          s->pmax[0][(size_t)cz * w + cx] = (uint16_t)mx;
+        }
+    } else {
+      int w2 = w * 2;
+      for (int cz = 0; cz < w; cz++)
+        for (int cx = 0; cx < w; cx++) {
+          int mn = 65535, mx = 0;
+          for (int dz = 0; dz < 2; dz++)
+            for (int dx = 0; dx < 2; dx++) {
+              size_t i = (size_t)(cz * 2 + dz) * w2 + (cx * 2 + dx);
+              if (s->pmin[l - 1][i] < mn) mn = s->pmin[l - 1][i];
+              if (s->pmax[l - 1][i] > mx) mx = s->pmax[l - 1][i];
+            }
+          s->pmin[l][(size_t)cz * w + cx] = (uint16_t)mn;
+          s->pmax[l][(size_t)cz * w + cx] = (uint16_t)mx;
+        }
+    }
+  }
+
+  if (dens >= 0) return make_balls(s, dens);
   return 0;
 }
 

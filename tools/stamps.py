@@ -4,9 +4,19 @@ import numpy as np
 import svo_raytracer_amd.scene as scene
 from svo_raytracer_amd import hiplib
 from svo_raytracer_amd.cameras import CAMERAS
-pool, _ = scene.build_scene(8192)
+# the cell: STAMPS_SCENE = terrain | caves, STAMPS_SEED, STAMPS_AMP, STAMPS_CAMERA = K0 | K1 | K2 (default: the bench line's)
+SCENE, SEED, AMP = os.environ.get("STAMPS_SCENE", "terrain"), int(os.environ.get("STAMPS_SEED", "1")), int(os.environ.get("STAMPS_AMP", "8"))
+CAMERA = os.environ.get("STAMPS_CAMERA", "K1")
+CELL = "%s_s%d_a%d_%s" % (SCENE, SEED, AMP, CAMERA)
+_cache = os.environ.get("SVO_SCENE_CACHE") and os.path.join(os.environ["SVO_SCENE_CACHE"], "caves_8192_s%d_a%d_d%d.npy" % (SEED, AMP, scene.CAVES_DENS))
 ctx = hiplib.HipContext(0)
-ctx.pool_upload(pool); ctx.resize(1920, 1080); ctx.set_camera(CAMERAS["K1"]); ctx.set_hit_records(False); ctx.set_pipeline(1)
+if SCENE == "terrain":      # on the GPU from its two maps, as bench.py does
+    ctx.build_from_heightmap(*scene.scene_maps(8192, SEED, AMP))
+elif _cache and os.path.exists(_cache):
+    ctx.pool_upload(np.load(_cache))
+else:
+    ctx.pool_upload(scene.build(SCENE, 8192, SEED, AMP)[0])
+ctx.resize(1920, 1080); ctx.set_camera(CAMERAS[CAMERA]); ctx.set_hit_records(False); ctx.set_pipeline(1)
 L = hiplib.lib()
 L.svo_debug_heads.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 import os, json
@@ -30,6 +40,7 @@ for wpc in [int(v) for v in os.environ.get("STAMPS_WAVES", "10,20").split(",")]:
     nw = 256 * wpc
     mixw = buf[24:32].view(np.uint64)   # lanes << 32 | trips: whole trip / descend / advance / pop
     trips = int(mixw[0] & 0xffffffff)
+    sect = {n: (int(mixw[i] & 0xffffffff), int(mixw[i] >> 32)) for i, n in enumerate(("trip", "descend", "advance", "pop"))}
     hist = buf[32:96].astype(np.float64)   # [L] = trips with exactly L lanes traversing (64 lanes: the rest)
     h64 = max(trips - hist.sum(), 0.0)
     full = np.concatenate([hist, [h64]])
@@ -43,8 +54,10 @@ for wpc in [int(v) for v in os.environ.get("STAMPS_WAVES", "10,20").split(",")]:
             "mean_lanes_traversing": round(float(mean), 2), "idle_lane_trips_pct": round(100 * (1 - mean / 64), 2),
             "trips_below_40_lanes_pct": round(100 * float(cum[39]), 2), "trips_with_all_64_pct": round(100 * float(full[64] / full.sum()), 2),
             "trips_per_wave": round(trips / nw, 1), "rounds_per_wave": round(float(d[2]) / nw, 1),
+            "sections": {n: {"share_of_trips_pct": round(100.0 * t / max(trips, 1), 1), "mean_lanes": round(l / max(t, 1), 1)} for n, (t, l) in sect.items()},
+            "ms_per_frame": round(float(ms[-1]), 4), "cell": CELL,
             "what": "SVO_STAMPS build of the same sources: per trip of the assembly loop, lanes traversing; %d persistent waves per CU, "
-                    "%d frame(s) per launch, one launch at a time, 8192^3 / 1920x1080 / mode 0 / K1" % (wpc, BATCH)}
+                    "%d frame(s) per launch, one launch at a time, 8192^3 %s seed %d amp %d / 1920x1080 / mode 0 / %s" % (wpc, BATCH, SCENE, SEED, AMP, CAMERA)}
         print("  histogram by 8 lanes:", " ".join("%.1f" % (100 * full[i:i + 8].sum() / full.sum()) for i in range(0, 64, 8)), "| 64: %.1f" % (100 * full[64] / full.sum()))
     if d[3] == 0:   # assembly loop: trips are not counted inside the asm block
         print("waves/cu", wpc, "thresh", t, "batch", BATCH, "ms/frame %.3f" % ms[-1], "rounds/wave %.1f trips/wave %.0f  cyc/round: round %.0f (shade part %.0f) + traversal %.0f; cyc/trip %.0f; round share %.1f %%" % (
@@ -59,5 +72,14 @@ if os.environ.get("STAMPS_JSON"):
     key = "waves10_batch4" if "waves10_batch4" in OUT else sorted(OUT)[0]
     e = dict(OUT[key], src_hash=bench.source_hash(), all=OUT)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "stamps_per_launch.json")
-    json.dump({"default": e}, open(path, "w"), indent=1)
-    print("wrote", path)
+    allj = {}
+    if os.path.exists(path):
+        try:
+            allj = json.load(open(path))
+        except Exception:
+            allj = {}
+    allj[CELL] = e
+    if CELL == "terrain_s1_a8_K1":
+        allj["default"] = e
+    json.dump(allj, open(path, "w"), indent=1)
+    print("wrote", path, CELL)
