@@ -102,7 +102,10 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=1, help="seed of the scene's integer noise")
     ap.add_argument("--amp", type=int, default=8, help="terrain amplitude in sixteenths of an octave's cell (8 = the default terrain)")
     ap.add_argument("--dens", type=int, default=None, help="caves: probability / 256 that a cell next to a surface holds a ball (default 64)")
-    ap.add_argument("--by-camera", type=int, default=1, help="also measure the default configuration from each of SURVEY 8(d)'s cameras "
+    ap.add_argument("--ref-loop", type=int, default=None, help="(default: as --default-abi) also time the reference's own loop -- per frame nSetCamera, nSetParams, nDispatchAsync, "
+                                                            "nReadPixel at the crosshair, through JNI-typed calls, wall clock (value_one_frame_at_a_time; "
+                                                            "one GPU, default pipeline)")
+    ap.add_argument("--by-camera", type=int, default=None, help="(default: as --default-abi) also measure the default configuration from each of SURVEY 8(d)'s cameras "
                                                              "K0 / K1 / K2, 100 verified steps each (value_by_camera; one GPU, C3 only)")
     ap.add_argument("--camera-path", choices=["static", "orbit"], default="static",
                     help="orbit: every timed frame carries its own camera (Camera.rotate + strafe through the host mirror) and "
@@ -149,6 +152,9 @@ def parse(argv=None):
     ap.add_argument("--as-rank", default=None, help="r/n: render what rank r of n would, on one GPU, no communication")
     args = ap.parse_args(argv)
     args.exchange_given = args.exchange is not None
+    for leg in ("ref_loop", "by_camera"):      # the legs behind the headline go together unless named
+        if getattr(args, leg) is None:
+            setattr(args, leg, args.default_abi)
     if args.exchange is None:
         args.exchange = "copy" if args.driver == "group" else "rccl"
     preset = PRESETS[args.config or "C3"]
@@ -277,7 +283,10 @@ def launch_ranks(args, argv=None, runner=run_rung):
     env = dict(os.environ, SVO_BENCH_CHILD="1")
     for driver, exchange in ladder(args):
         cmd = rung_command(args, driver, exchange, argv)
-        rc, line, last_err = runner(cmd, args.rung_timeout, env)
+        # the copy exchange needs no collective on device memory: its ranks keep the control plane on gloo, so a node whose RCCL
+        # failed the rung before does not fail this one the same way (probe_env does the same for the copy probe)
+        renv = dict(env, SVO_BENCH_BACKEND="gloo") if (driver, exchange) == ("torch", "copy") else env
+        rc, line, last_err = runner(cmd, args.rung_timeout, renv)
         ok = rc == 0 and line is not None and line.get("verified") is not False
         if ok:
             line["fallback_from"] = failed
@@ -293,7 +302,9 @@ def launch_ranks(args, argv=None, runner=run_rung):
 
 
 KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop2.h", "svo_trav2.h", "svo_derive.hip.h", "svo_descword.h", "svo_travloop.h", "svo_trav.h",
-                  "svo_device.h", "svo_fused.hip.h", "svo_kernels.h", "Makefile")
+                  "svo_device.h", "svo_fused.hip.h", "svo_kernels.h", "svo_travloop3.h", "svo_persist2.hip.h", "Makefile")
+# environment switches that select another kernel or another data path than the default's: PMC / stamps figures are keyed by them
+KERNEL_ENV = ("SVO_SPARE", "SVO_RC_TABLE", "SVO_NORMAL_TABLE", "SVO_DERIVED", "SVO_FORCE_CAMS", "SVO_HIP_LIB")
 
 
 def source_hash():
@@ -336,6 +347,10 @@ def pmc_key(args, width, height, nbuf, batch):
         key += "_amp%d" % args.amp
     if args.mirror:
         key += "_mirror%x" % args.mirror
+    for e in KERNEL_ENV:      # (a run on another kernel / library never picks up the default kernel's counters)
+        v = os.environ.get(e)
+        if v not in (None, ""):
+            key += "_%s=%s" % (e, os.path.basename(v))
     return key
 
 
@@ -478,6 +493,122 @@ def run_default_abi(pool, W, H, cam, args, nbuf, batch, rays_per_frame, first_ti
         nDestroy(j)
 
 
+def run_reference_loop(pool, W, H, cam, args, nframes=300, warm=30):
+    """The reference's own loop as the loop it is (Main.updateEarly, Main.java:132-146, 257-289): per frame the uniforms
+    (nSetCamera, nSetParams), the dispatch (nDispatchAsync = glDispatchCompute + glMemoryBarrier, which return at once) and the
+    crosshair read-back of THAT frame (nReadPixel at the image centre: Main reads it at the top of the next updateEarly, before
+    anything else) -- through JNI-typed calls only, on a context of its own, timed by the wall clock around `nframes` frames and a
+    final nSync.  Once with a static camera (frameNumber advances every frame) and once with one that moves every frame
+    (frameNumber 1, Main.java:225-233, 275); rays of the counted frames through nCountFrame on the same context; the last frame
+    of each leg verified against the CPU oracle.  Then the static leg again without the alternating image sets, and without
+    sets and pick (= round 5's loop: a whole-frame wait per pick), for the A/B the header of svo_dispatch_async cites."""
+    import ctypes
+    import numpy as np
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import orbit_path
+    L = hiplib.lib()
+    vp, jint, jlong, jfloat = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+    def fn(name, res, *a):
+        f = getattr(L, "Java_src_engine_HipRenderer_" + name)
+        f.restype = res
+        f.argtypes = [vp, vp] + list(a)
+        return lambda *v: f(None, None, *v)
+
+    nCreate, nDestroy = fn("nCreate", jlong, jint), fn("nDestroy", jint, jlong)
+    nPoolUpload = fn("nPoolUpload", jint, jlong, jlong, jlong)
+    nSetCamera = fn("nSetCamera", jint, jlong, *([jfloat] * 15))
+    nSetParams = fn("nSetParams", jint, jlong, *([jint] * 7))
+    nResize = fn("nResize", jint, jlong, jint, jint)
+    nDispatchAsync, nSync = fn("nDispatchAsync", jint, jlong), fn("nSync", jint, jlong)
+    nReadPixel = fn("nReadPixel", jint, jlong, jint, jint, jlong, jlong, jlong)
+    nReadColor, nReadDepth = fn("nReadColor", jint, jlong, jlong), fn("nReadDepth", jint, jlong, jlong)
+    nSetHitRecords = fn("nSetHitRecords", jint, jlong, jint)
+    nCountFrame = fn("nCountFrame", jint, jlong, jlong)
+    nDerivedInfo = fn("nDerivedInfo", jlong, jlong, jlong)
+    nPickInfo = fn("nPickInfo", jlong, jlong, jlong, jlong)
+    nSetPick, nSetOverlap = fn("nSetPick", jint, jlong, jint, jint), fn("nSetOverlap", jint, jlong, jint)
+
+    def ok(rc, what):
+        if rc < 0:
+            raise RuntimeError("%s returned %d" % (what, rc))
+        return rc
+
+    j = nCreate(0)
+    if j == 0:
+        raise RuntimeError("nCreate returned 0")
+    try:
+        ok(nPoolUpload(j, pool.ctypes.data, pool.size), "nPoolUpload")
+        ok(nResize(j, W, H), "nResize")
+        ok(nSetHitRecords(j, 1 if args.hits else 0), "nSetHitRecords")
+        ok(nDerivedInfo(j, 0), "nDerivedInfo")
+        if os.environ.get("SVO_LOOP_WAVES"):      # experiment knob (tools/loop_shape.py): the launch shape of the loop's dispatches
+            ok(fn("nSetTuning", jint, jlong, jint, jint)(j, int(os.environ["SVO_LOOP_WAVES"]), int(os.environ.get("SVO_LOOP_THRESH", "0"))), "nSetTuning")
+        cx, cy = W // 2, H // 2
+        one = np.zeros(1, np.float32)
+        st = hiplib.Stats()
+
+        def frames(cams, fnums, n, first):
+            """n frames of the loop; frame i uses cams[i % len] and frame number fnums(i)"""
+            for i in range(first, first + n):
+                ok(nSetCamera(j, *cams[i % len(cams)]), "nSetCamera")
+                ok(nSetParams(j, fnums(i), args.mode, int(pool.size), 0, args.bounces, args.mirror, 1), "nSetParams")
+                ok(nDispatchAsync(j), "nDispatchAsync")
+                ok(nReadPixel(j, cx, cy, 0, one.ctypes.data, 0), "nReadPixel")
+
+        def leg(cams, fnums, what):
+            camsf = [[float(v) for v in np.asarray(c, np.float32).reshape(-1)] for c in cams]
+            rays = []
+            for i in sorted({warm + (nframes - 1) * k // 4 for k in range(5)}):
+                ok(nSetCamera(j, *camsf[i % len(camsf)]), "nSetCamera")
+                ok(nSetParams(j, fnums(i), args.mode, int(pool.size), 0, args.bounces, args.mirror, 1), "nSetParams")
+                ok(nCountFrame(j, ctypes.addressof(st)), "nCountFrame")
+                rays.append(int(st.rays))
+            frames(camsf, fnums, warm, 0)
+            ok(nSync(j), "nSync")
+            m0 = nPickInfo(j, 0, 0)
+            t0 = time.perf_counter()
+            frames(camsf, fnums, nframes, warm)
+            ok(nSync(j), "nSync")
+            dt = time.perf_counter() - t0
+            early = nPickInfo(j, 0, 0) - m0
+            r = {"value": round(float(np.mean(rays)) * nframes / dt / 1e6, 2), "unit": "Mrays/s", "frames": nframes,
+                 "ms_per_frame": round(dt / nframes * 1e3, 4), "rays_per_frame": int(np.mean(rays)), "picks_answered_before_the_frame_ended": int(early),
+                 "what": what}
+            if args.verify:
+                from oracle import oracle   # the checker; behind the timed region
+                last = warm + nframes - 1
+                rgba, depth = np.zeros((H, W, 4), np.uint8), np.zeros((H, W), np.float32)
+                ok(nReadColor(j, rgba.ctypes.data), "nReadColor")
+                ok(nReadDepth(j, depth.ctypes.data), "nReadDepth")
+                step, bad, npx = 32, 0, 0
+                xs = np.arange(0, W, step)
+                for y in list(range(0, H, step)) + [cy]:
+                    ref = oracle.render(pool, W, H, np.asarray(cams[last % len(cams)], np.float32), fnums(last), args.mode, bounces=args.bounces,
+                                        mirror_mask=args.mirror, spp=1, rows=(y, y + 1), xstep=step if y != cy else 1, want_hits=False)
+                    sel = xs if y != cy else np.array([cx])
+                    bad += int((rgba[y, sel] != ref["rgba"][y, sel]).any(axis=1).sum())
+                    bad += int((depth.view(np.uint32)[y, sel] != ref["depth"].view(np.uint32)[y, sel]).sum())
+                    npx += int(sel.size)
+                bad += int(one.view(np.uint32)[0] != depth.view(np.uint32)[cy, cx])      # the last pick = the image's crosshair pixel
+                r["verified"] = bad == 0
+                r["verification"] = "last frame (frameNumber %d): every %d-th pixel + the crosshair (%d pixels) and the last pick vs the CPU oracle: %d mismatches" % (
+                    fnums(last), step, npx, bad)
+            return r
+
+        static = leg([cam], lambda i: 2 + i, "static camera, frameNumber 2, 3, ... (Main.java:275)")
+        mcams, _ = orbit_path(warm + nframes + 4, start=args.camera)
+        moving = leg(list(mcams), lambda i: 1, "a camera that moves every frame (Camera.rotate + strafe through the host mirror), frameNumber 1 on every frame")
+        ok(nSetOverlap(j, 0), "nSetOverlap")
+        pick_only = leg([cam], lambda i: 2 + i, "static camera; one stream and one image set (svo_set_overlap 0), pick from the mail")
+        ok(nSetPick(j, -1, -1), "nSetPick")
+        neither = leg([cam], lambda i: 2 + i, "static camera; one stream, one image set, no pick: every read-back waits for its frame (round 5's loop)")
+        return {"static": static, "moving": moving, "without_overlap": pick_only, "without_overlap_and_pick": neither,
+                "calls_per_frame": "nSetCamera, nSetParams, nDispatchAsync, nReadPixel(%d, %d) -- JNI-typed exports, wall clock, a context of its own" % (cx, cy)}
+    finally:
+        nDestroy(j)
+
+
 def stamps_for(key):
     """Mean lanes traversing per trip of the assembly loop (tools/stamps.py on an -DSVO_STAMPS=1 build of the same sources:
     profiles/stamps_per_launch.json) -- only if taken on the current kernel sources."""
@@ -485,7 +616,7 @@ def stamps_for(key):
         j = json.load(open(os.path.join(ROOT, "profiles", "stamps_per_launch.json")))
     except Exception:
         return None
-    e = j.get(key) or j.get("default")
+    e = j.get(key)      # (no fall-back to another launch shape's entry: a line carries its own shape's figures or none)
     if not e or e.get("src_hash") != source_hash():
         return None
     return {k: v for k, v in e.items() if k != "src_hash"}
@@ -498,11 +629,12 @@ def probe_command(args, exchange):
             "--long-steps", "0", "--isolated", "0", "--probe", "0", "--driver", "torch", "--exchange", exchange]
 
 
-def probe_env(exchange, attempt):
+def probe_env(exchange, attempt, port=None):
     """The environment of a probe child: this rank's RANK / LOCAL_RANK / WORLD_SIZE, a rendezvous of its own (the launcher's
-    store is the parent job's: the children meet at MASTER_PORT + 101 + attempt through a TCP store rank 0's child opens)."""
+    store is the parent job's: the children meet through a TCP store rank 0's child opens at `port` -- a free port rank 0 of the
+    parent job picked and the gloo group carried to every rank; MASTER_PORT + 101 + attempt without one)."""
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 101 + attempt)
+    env["MASTER_PORT"] = str(port if port else int(os.environ.get("MASTER_PORT", "29500")) + 101 + attempt)
     env["SVO_BENCH_CHILD"] = "1"
     if exchange == "copy":
         env["SVO_BENCH_BACKEND"] = "gloo"      # the copy exchange needs no collective on device memory: control plane only
@@ -518,7 +650,10 @@ def negotiate_exchange(args, dist, torch, runner=run_rung):
     tried = []
     dist.init_process_group("gloo")
     for attempt, exchange in enumerate(("rccl", "copy")):
-        rc, line, err = runner(probe_command(args, exchange), args.probe_timeout, probe_env(exchange, attempt))
+        # a rendezvous port nobody holds: rank 0 asks the kernel for one, everybody learns it over the group that exists already
+        pt = torch.tensor([_free_port() if dist.get_rank() == 0 else 0], dtype=torch.int32)
+        dist.broadcast(pt, src=0)
+        rc, line, err = runner(probe_command(args, exchange), args.probe_timeout, probe_env(exchange, attempt, int(pt.item())))
         mine = rc == 0 and (line is None or line.get("verified") is not False)
         t = torch.tensor([1 if mine else 0], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -890,6 +1025,17 @@ def main(argv=None, ctx_factory=None):
         except Exception as e:     # noqa: BLE001
             default_abi = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- the reference's own loop, one frame at a time, as the loop it is: wall clock through JNI-typed calls
+    ref_loop = None
+    if (args.ref_loop and path is None and args.seq == 1 and ngpu == 1 and as_rank is None and not stub and not group_mode
+            and args.pipeline == 1 and not args.beam and args.spp == 1 and rank == 0):
+        try:
+            ref_loop = run_reference_loop(pool, W, H_total, cam, args)
+            if args.verify and any(v.get("verified") is False for v in ref_loop.values() if isinstance(v, dict)):
+                verified = False
+        except Exception as e:     # noqa: BLE001
+            ref_loop = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- kernel time by HIP events on the dispatch streams; then one frame at a time with the GPU to itself ----
     # (svo_ring_query: events around every submission on its slot's stream; whole batches only, so that every launch
     # averaged carries the same number of frames)
@@ -919,6 +1065,7 @@ def main(argv=None, ctx_factory=None):
             "traffic": (int((pmc["fetch_size_kb"] * 1024 * 2 + pmc["write_size_kb"] * 1024) / batch) if pmc else None),
             "traffic_note": "per frame: (FETCH_SIZE x 2 + WRITE_SIZE) KB of separate rocprofv3 --pmc passes; the x 2 is the scattered-load "
                             "correction of profiles/r01_fetch_size_calibration.txt (gfx950 tallies a 128-byte request as 64)",
+            "frac_long_run": (round(my_alg / (long_run[1] / long_run[0]) / 1e9 / HBM_PEAK_GBS, 5) if long_run else None),
             "kernel_ms": round(kernel_ms, 4), "launches_in_flight": nbuf, "frames_per_launch": batch,
             "kernel_ms_isolated": round(kernel_ms_isolated, 4) if kernel_ms_isolated is not None else None,
             "alg_bytes_per_launch": int(my_alg * batch),
@@ -965,7 +1112,11 @@ def main(argv=None, ctx_factory=None):
             stripes = "what-if: the stripes of rank %d of %d on one GPU, no communication" % as_rank
         # the same frame through the reference's own loop -- one dispatch, then the crosshair read-back, then the next
         # (Main.updateEarly, Main.java:132-146, 257-289): what `value` would be without frames in flight
-        one_at_a_time = (rays / (kernel_ms_isolated * 1e-3) / 1e6) if (kernel_ms_isolated and ngpu == 1 and as_rank is None and path is None) else None
+        # value_one_frame_at_a_time = that loop's wall clock (static camera; reference_loop has the moving camera and the A/B
+        # legs); kernel_rate_isolated = rays / HIP-event time of back-to-back single-frame launches on one stream (what rounds
+        # 1-5 printed under the first name: no read-back, no host in the loop)
+        kernel_rate_isolated = (rays / (kernel_ms_isolated * 1e-3) / 1e6) if (kernel_ms_isolated and ngpu == 1 and as_rank is None and path is None) else None
+        one_at_a_time = ref_loop["static"]["value"] if (ref_loop and "static" in ref_loop) else None
         line = {
             "metric": "Mrays/s (primary + 1 bounce) at 1920x1080, 8192^3 SVO",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
@@ -974,6 +1125,9 @@ def main(argv=None, ctx_factory=None):
             "verified": verified,
             "frames_in_flight": nbuf * batch,
             "value_one_frame_at_a_time": round(one_at_a_time, 2) if one_at_a_time else None,
+            "value_one_frame_at_a_time_moving_camera": (ref_loop["moving"]["value"] if (ref_loop and "moving" in ref_loop) else None),
+            "reference_loop": ref_loop,
+            "kernel_rate_isolated": round(kernel_rate_isolated, 2) if kernel_rate_isolated else None,
             # the default configuration with a camera that moves every frame (None where it was not measured)
             "value_moving_camera": moving["value"] if moving else None,
             "moving_camera": moving,

@@ -71,6 +71,10 @@ typedef struct svo_stats {
 
 /* ---- lifetime ------------------------------------------------------------------ */
 /* replaces: GL context + Renderer singleton creation (Window.java:24-50, Renderer.java:14-36) */
+/* which build of the library this is: bit 0 = the comparators and A/B switches are built in (libsvohip_variants.so: pipeline 2,
+ * the spare-ray kernel, the SVO_* environment switches; the product library libsvohip.so reports 0 there), bit 1 = the traversal
+ * trips are the hand-written gfx950 assembly (0: hipcc's translation of the same statement, libsvohip_cxxloop.so) */
+int svo_build_info(void);
 int svo_create(int device, svo_ctx **out);
 int svo_destroy(svo_ctx *ctx);
 const char *svo_last_error(const svo_ctx *ctx); /* replaces Renderer.printGLErrors, Renderer.java:160-165 */
@@ -241,6 +245,9 @@ int svo_dispatch_async(svo_ctx *ctx);
  *     (tests/test_gpu_pick.py). */
 int svo_set_pick(svo_ctx *ctx, int x, int y);
 int svo_set_overlap(svo_ctx *ctx, int enabled);
+/* the pick position in force (-1, -1: none) and how many svo_read_pixel calls were answered from the mail / by waiting for
+ * their frame since the context was made.  Any pointer may be NULL. */
+int svo_pick_info(svo_ctx *ctx, int *x, int *y, uint64_t *from_mail, uint64_t *waited);
 int svo_sync(svo_ctx *ctx);
 /* run the frame once more with counters on and fill svo_stats (untimed diagnostic pass) */
 int svo_count_frame(svo_ctx *ctx, svo_stats *out);

@@ -73,6 +73,9 @@ jint Java_src_engine_HipRenderer_nDispatchAsync(void *env, void *cls, jlong ctx)
 jint Java_src_engine_HipRenderer_nSync(void *env, void *cls, jlong ctx);
 jint Java_src_engine_HipRenderer_nSetPick(void *env, void *cls, jlong ctx, jint x, jint y);       /* svo_set_pick */
 jint Java_src_engine_HipRenderer_nSetOverlap(void *env, void *cls, jlong ctx, jint enabled);     /* svo_set_overlap */
+/* svo_pick_info: read-backs answered from the mail (or a negative status); two ints (x, y of the pick in force) at xy_addr and
+ * the read-backs that waited for their frame at waited_addr (a long) unless 0 */
+jlong Java_src_engine_HipRenderer_nPickInfo(void *env, void *cls, jlong ctx, jlong xy_addr, jlong waited_addr);
 /* hipStream_t as a long; 0 = the library's own stream */
 jint Java_src_engine_HipRenderer_nSetStream(void *env, void *cls, jlong ctx, jlong hip_stream);
 jint Java_src_engine_HipRenderer_nSetPipeline(void *env, void *cls, jlong ctx, jint pipeline);

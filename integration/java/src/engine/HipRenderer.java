@@ -351,6 +351,11 @@ public class HipRenderer {
     check(nSetPick(ctx, x, y));
   }
 
+  /** svo_pick_info: how many readDepthPixel calls were answered without waiting for their frame. */
+  public long picksAnsweredEarly() {
+    return nPickInfo(ctx, 0L, 0L);
+  }
+
   /**
    * svo_set_overlap: dispatchCompute alternates two {stream, image} sets so that frame N + 1 starts in frame N's tail (default
    * on); read-backs always see the last dispatched frame.  false = one stream, one image set.
@@ -616,6 +621,7 @@ public class HipRenderer {
   private static native int nSync(long ctx);
   private static native int nSetPick(long ctx, int x, int y);
   private static native int nSetOverlap(long ctx, int enabled);
+  private static native long nPickInfo(long ctx, long xyAddr, long waitedAddr);
   private static native int nSetStream(long ctx, long hipStream);
   private static native int nSetPipeline(long ctx, int pipeline);
   private static native int nSetTuning(long ctx, int wavesPerCu, int roundThresholdSixteenths);

@@ -381,7 +381,11 @@ __global__ __launch_bounds__(256) void unroll_new_kernel(const uint8_t *pool_bas
 inline hipError_t refresh_table(Table &t, const uint8_t *d_pool, uint64_t pool_len64, uint64_t start64, uint64_t end64,
                                 hipStream_t stream, bool *refreshed) {
   *refreshed = false;
+#if defined(SVO_VARIANTS) && SVO_VARIANTS
   static const bool log = []() { const char *e = getenv("SVO_DERIVED_REFRESH_LOG"); return e && e[0] == '1'; }();
+#else
+  const bool log = false;
+#endif
   auto gave_up = [&](const char *why, uint32_t flags) {
     if (log) fprintf(stderr, "[svo] table refresh [%llu, %llu) gave up: %s (flags %u, %u of %zu descriptors)\n", (unsigned long long)start64,
                      (unsigned long long)end64, why, flags, t.count, t.cap);

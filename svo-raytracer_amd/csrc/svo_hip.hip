@@ -11,12 +11,23 @@
 #include <string>
 #include <vector>
 
+// SVO_VARIANTS=0 (libsvohip.so, what a host loads): pipeline 1 -- persistent waves over the descriptor table, with the record
+// walk for pools the table cannot state -- and pipeline 0 (the reference's one-thread-per-pixel decomposition: its kernel is also
+// the counting pass of svo_count_frame), the beam pass, the builder, the ring, the group.
+// SVO_VARIANTS=1 (libsvohip_variants.so, `make variants`; loaded by the tests that compare against them, like cxxloop): the same
+// plus the comparators -- pipeline 2 (staged wavefront tracing), the spare-ray kernel of round 5 (SVO_SPARE=1) -- and the
+// environment switches of the A/B runs (SVO_DERIVED, SVO_RC_TABLE, SVO_NORMAL_TABLE, SVO_FORCE_CAMS, SVO_PERSIST_*, ...).
+#ifndef SVO_VARIANTS
+#define SVO_VARIANTS 0
+#endif
 #include "svo_fused.hip.h"
 #include "svo_persistent.hip.h"
-#if SVO_ASM_LOOP
+#if SVO_ASM_LOOP && SVO_VARIANTS
 #include "svo_persist2.hip.h"
 #endif
+#if SVO_VARIANTS
 #include "svo_wavefront.hip.h"
+#endif
 #include "svo_build.hip.h"
 #include "svo_beam.hip.h"
 #include "svo_derive.hip.h"
@@ -72,6 +83,7 @@ struct svo_ctx {
   bool pick_default = true;    // follows the image centre (the crosshair, Main.java:139-141) until svo_set_pick names a pixel
   uint32_t *pick_mail = nullptr;   // kPickSlots x kPickWords words of host memory the device writes
   uint32_t pick_seq = 0;       // sequence number of the last dispatch that carried the pick
+  uint64_t pick_from_mail = 0, pick_waited = 0;   // svo_read_pixel calls answered from the mail / by waiting for the frame (svo_pick_info)
   bool pick_live = false;      // the current set's last dispatch carried it (cleared by everything else that renders into the set)
   int pick_live_x = -1, pick_live_y = -1;
   DeviceCounters *d_counters = nullptr;
@@ -90,7 +102,9 @@ struct svo_ctx {
   derive::Table dt;
   bool derived_valid = false;     // cleared by everything that changes the pool
   int derived_mode = 1;           // 0 = always walk the records, 1 = walk the table when there is one
+#if SVO_VARIANTS
   WavefrontBuffers wf;
+#endif
   PersistBuffers pb;
   // frames in flight behind the boundary (svo_ring_*): per slot a stream of its own, output buffers for up to
   // ring_frames consecutive frames, and the events around its last submission
@@ -197,7 +211,9 @@ static void free_outputs(svo_ctx *c) {
   if (c->cur_set == 1 && (c->stream == c->alt_stream || c->stream == nullptr)) c->stream = c->own_stream;
   c->cur_set = 0; c->alt_inflight = false; c->pick_live = false;
   if (!c->external_outputs) { c->d_color = nullptr; c->d_depth = nullptr; c->d_hits = nullptr; }
+#if SVO_VARIANTS
   wavefront_free(c->wf);
+#endif
   persist_free(c->pb);
   for (int i = 0; i < svo_ctx::kBeamSets; i++) {
     if (c->d_beam[i]) (void)hipFree(c->d_beam[i]);
@@ -231,6 +247,8 @@ int svo_destroy(svo_ctx *c) {
 }
 
 const char *svo_last_error(const svo_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int svo_build_info(void) { return (SVO_VARIANTS ? 1 : 0) | (SVO_ASM_LOOP ? 2 : 0); }
 
 // ---------------------------------------------------------------- pool
 static int ensure_pool_capacity(svo_ctx *c, uint64_t need_len, bool keep) {
@@ -302,7 +320,11 @@ int svo_pool_upload(svo_ctx *c, const void *host, uint64_t nbytes) {
 int svo_pool_update(svo_ctx *c, const void *host_base, uint64_t start, uint64_t end) {
   // a walkable descriptor table follows a ranged update instead of being rebuilt (derive::refresh_table): an SDF brush
   // stroke is two such updates (Main.java:349-350), the table of the 8192^3 scene takes 6.7 ms to build
+#if SVO_VARIANTS
   static const bool follow = []() { const char *e = getenv("SVO_DERIVED_REFRESH"); return !(e && e[0] == '0'); }();
+#else
+  const bool follow = true;
+#endif
   const bool had_table = c && follow && c->derived_valid && c->dt.ok;
   if (c) { c->beam_live_valid = false; c->derived_valid = false; }   // the pool is about to change (or to be handed out for writing)
   if (!c || !host_base) return fail(c, SVO_E_INVALID, "svo_pool_update: null buffer");
@@ -517,6 +539,10 @@ int svo_set_stripes(svo_ctx *c, int first_tile_row, int tile_row_step, int n_til
 
 int svo_set_pipeline(svo_ctx *c, int pipeline) {
   if (!c || pipeline < 0 || pipeline > 2) return fail(c, SVO_E_INVALID, "pipeline must be 0, 1 or 2");
+#if !SVO_VARIANTS
+  if (pipeline == 2)
+    return fail(c, SVO_E_INVALID, "pipeline 2 (staged wavefront tracing, a comparator) is built into libsvohip_variants.so, not into this library");
+#endif
   c->pipeline = pipeline;
   return SVO_OK;
 }
@@ -526,8 +552,10 @@ int svo_set_tuning(svo_ctx *c, int waves_per_cu, int round_threshold_sixteenths)
     return fail(c, SVO_E_INVALID, "svo_set_tuning: bad values");
   c->pb.waves_per_cu = waves_per_cu;
   c->pb.thresh_num = round_threshold_sixteenths;   // 0 = the running kernel's own default
+#if SVO_VARIANTS
   c->wf.waves_per_cu = waves_per_cu;
   c->wf.thresh_num = round_threshold_sixteenths ? round_threshold_sixteenths : 12;
+#endif
   return SVO_OK;
 }
 
@@ -622,6 +650,15 @@ int svo_set_stream(svo_ctx *c, void *hip_stream) {
 int svo_set_overlap(svo_ctx *c, int enabled) {
   if (!c) return SVO_E_INVALID;
   c->overlap = enabled ? 1 : 0;
+  return SVO_OK;
+}
+
+int svo_pick_info(svo_ctx *c, int *x, int *y, uint64_t *from_mail, uint64_t *waited) {
+  if (!c) return SVO_E_INVALID;
+  if (x) *x = c->pick_x;
+  if (y) *y = c->pick_y;
+  if (from_mail) *from_mail = c->pick_from_mail;
+  if (waited) *waited = c->pick_waited;
   return SVO_OK;
 }
 
@@ -809,7 +846,11 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
   int rc = SVO_OK;
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(DeviceCounters), c->stream));
   if (c->pipeline == 1 && !count) {
+#if SVO_VARIANTS
     static const int env_mode = getenv("SVO_DERIVED") ? atoi(getenv("SVO_DERIVED")) : -1;   // A/B override
+#else
+    const int env_mode = -1;
+#endif
     const int mode = env_mode >= 0 ? env_mode : c->derived_mode;
     if (mode != 0 && (rc = ensure_derived(c)) != SVO_OK) return rc;
     const bool walk_table = mode != 0 && c->dt.ok;   // not derivable (deeper than 13 levels, cyclic): the records are walked
@@ -819,11 +860,13 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
     if (rc) return fail(c, SVO_E_HIP, std::string("persistent pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
+#if SVO_VARIANTS
   if (c->pipeline == 2 && !count) {
     rc = wavefront_launch(c->wf, c->d_pool, f, color, depth, hits, out_elems(c, f), c->stream);
     if (rc) return fail(c, SVO_E_HIP, std::string("wavefront pipeline: ") + hipGetErrorString((hipError_t)rc));
     return SVO_OK;
   }
+#endif
   const int per = (f.ntiles + 7) / 8;
   dim3 grid((unsigned)(per * 8)), block(64);
   if (count)
@@ -1136,7 +1179,11 @@ static int ring_submit(svo_ctx *c, int frame_number, int nframes, const FrameVar
 }
 
 int svo_ring_submit(svo_ctx *c, int frame_number, int nframes, int *slot) {
+#if SVO_VARIANTS
   static const bool force_cams = getenv("SVO_FORCE_CAMS") && atoi(getenv("SVO_FORCE_CAMS")) != 0;   // A/B: the kCams kernel on a static camera
+#else
+  const bool force_cams = false;
+#endif
   if (force_cams && c && nframes > 1 && nframes <= 64 && !c->use_beam && !c->progressive) {
     FrameVar v[64];
     for (int k = 0; k < nframes; k++) { memcpy(v[k].cam, c->cam, sizeof v[k].cam); v[k].frame_number = frame_number + k; }
@@ -1370,12 +1417,14 @@ int svo_read_pixel(svo_ctx *c, int x, int y, void *rgba8, float *depth, svo_hit 
 #endif
     }
     if (got) {
+      c->pick_from_mail++;
       if (rgba8) { const uint32_t v = m[1]; memcpy(rgba8, &v, 4); }
       if (depth) { const uint32_t v = m[2]; memcpy(depth, &v, 4); }
       if (hit) { uint32_t h[4] = {m[4], m[5], m[6], m[7]}; memcpy(hit, h, 16); }
       return SVO_OK;
     }
   }
+  c->pick_waited++;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t o = (size_t)y * (size_t)c->width + (size_t)x;
   if (rgba8) HIPCHK(c, hipMemcpy(rgba8, c->d_color + o, 4, hipMemcpyDeviceToHost));
@@ -1401,12 +1450,12 @@ extern "C" {
 
 #ifdef SVO_STAMPS
 // diagnostic builds only: the diagnostics words of the persistent pipeline's last counter set (16 x u64, then the
-// 64-word histogram of lanes traversing per trip): 384 bytes
+// 64-word histograms of lanes traversing per trip and of lanes in the POP section, 8 x u64 of a round's parts): 704 bytes
 int svo_debug_heads(svo_ctx *c, void *out) {
   if (!c || !out || !c->pb.heads) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemcpy(out, c->pb.heads + (size_t)((c->pb.frames - 1) % kHeadSets) * kHeadWords + 8 * kHeadStride, 384, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out, c->pb.heads + (size_t)((c->pb.frames - 1) % kHeadSets) * kHeadWords + 8 * kHeadStride, 704, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
 #endif

@@ -85,6 +85,15 @@ jint Java_src_engine_HipRenderer_nDispatchAsync(void *, void *, jlong ctx) { ret
 jint Java_src_engine_HipRenderer_nSync(void *, void *, jlong ctx) { return svo_sync(CTX(ctx)); }
 jint Java_src_engine_HipRenderer_nSetPick(void *, void *, jlong ctx, jint x, jint y) { return svo_set_pick(CTX(ctx), x, y); }
 jint Java_src_engine_HipRenderer_nSetOverlap(void *, void *, jlong ctx, jint enabled) { return svo_set_overlap(CTX(ctx), enabled); }
+jlong Java_src_engine_HipRenderer_nPickInfo(void *, void *, jlong ctx, jlong xy_addr, jlong waited_addr) {
+  int xy[2] = {-1, -1};
+  uint64_t from_mail = 0, waited = 0;
+  const int rc = svo_pick_info(CTX(ctx), &xy[0], &xy[1], &from_mail, &waited);
+  if (rc != SVO_OK) return (jlong)rc;
+  if (xy_addr) { ((jint *)(intptr_t)xy_addr)[0] = xy[0]; ((jint *)(intptr_t)xy_addr)[1] = xy[1]; }
+  if (waited_addr) *(jlong *)(intptr_t)waited_addr = (jlong)waited;
+  return (jlong)from_mail;
+}
 jint Java_src_engine_HipRenderer_nSetStream(void *, void *, jlong ctx, jlong hip_stream) {
   return svo_set_stream(CTX(ctx), (void *)(intptr_t)hip_stream);
 }

@@ -35,7 +35,8 @@ namespace svo {
 // became more frequent; with separate lines it stays below 500.
 constexpr int kHeadStride = 32;
 #ifdef SVO_STAMPS
-constexpr int kHeadWords = 8 * kHeadStride + 32 + 64;  // + diagnostics words + the histogram of lanes traversing per trip
+constexpr int kHeadWords = 8 * kHeadStride + 32 + 64 + 64 + 16;  // + diagnostics words + the histograms of lanes traversing / popping per trip
+                                                                   // + 8 x u64: cycles of a round by part
 #else
 constexpr int kHeadWords = 8 * kHeadStride + 32;  // + diagnostics words
 #endif
@@ -80,6 +81,9 @@ struct PersistArgs {
   uint32_t pick_seq;
   int pick_band, pick_j; // its tile: the band and the tile slot inside the band (after the launch's column direction)
 };
+#ifndef SVO_PICK
+#define SVO_PICK 1   // 0 (A/B only): the kernels carry no pick code; svo_read_pixel then always takes the waiting path
+#endif
 constexpr int kPickWords = 8;
 constexpr int kPickSlots = 8;   // mail slots, one per dispatch, re-used round-robin
 
@@ -122,6 +126,7 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
     if (px < 10 && py < 10) col = a.f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
     const uint32_t rgba = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
     a.color[pix] = rgba;
+#if SVO_PICK
     if (a.pick_mail != nullptr && pix == a.pick_pix) {   // one lane of one wave per frame
       uint32_t *m = a.pick_mail;
       m[1] = rgba; m[2] = __float_as_uint(depth); m[3] = 0u;
@@ -131,6 +136,7 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
       __threadfence_system();
       __hip_atomic_store(m, a.pick_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#endif
   } else if (a.fold > 1) {
     // every sample in a slot of its own, [frame][tile][sample][channel][pixel of the tile]: the 64 values of a tile's
     // sample and channel share two cache lines, and the kernel that adds the samples up in order reads them coalesced
@@ -319,7 +325,10 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
   unsigned long long st_round = 0, st_trav = 0, st_nround = 0, st_ntrip = 0, st_shade = 0, st_load = 0, st_t0 = __builtin_readcyclecounter();
   const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device
   unsigned long long st_dry = 0;
-  uint32_t st_mix[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // trips / lanes, by section (trav_loop); [8]: per-lane histogram word (trav_loop2)
+  uint32_t st_mix[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // trips / lanes, by section (trav_loop); [8], [9]: per-lane histogram words (trav_loop2)
+  // a round by part (round 6): the cast's result (hit-record fetch + decode), the shading arithmetic, the pixel store, the refill
+  // (counter draw + the new pixels' primary direction / random number), the ray set-up (three IEEE divisions + the stack column)
+  unsigned long long st_part[5] = {0, 0, 0, 0, 0}, st_lanes_shaded = 0, st_lanes_refilled = 0, st_lanes_init = 0;
 #endif
   for (;;) {
     // ---------------- finished lanes: shade, then regenerate the next ray in place or retire
@@ -329,8 +338,16 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
     bool emit = false, ninit = false, icone = false;
     V3 ecol = mk(0.f, 0.f, 0.f), io = mk(0.f, 0.f, 0.f);
     float edepth = 0.0f, its = 0.0f;
+#ifdef SVO_STAMPS
+    unsigned long long st_r1 = 0, st_r2 = 0;
+    st_lanes_shaded += (unsigned long long)__builtin_popcountll(__ballot(status >= ST_HIT));
+#endif
     if (status >= ST_HIT) {
       const Cast c = walk.result(t, status);
+#ifdef SVO_STAMPS
+      asm volatile("" ::"v"(c.t), "v"(c.pointer), "v"(c.normal.x), "v"(c.voxel_pos.x), "v"(c.value) : "memory");   // the record is here
+      st_r1 = __builtin_readcyclecounter();
+#endif
       status = ST_IDLE;
       const uint32_t segn = seg & 0xffu, smp = seg >> 8;   // smp: sample | frame of the batch << 16
       if (segn == 0u && (smp & 0xffffu) == 0u && f.write_hits && a.sample == 0) {
@@ -415,10 +432,20 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
         if (c.hit) { ecol = mk(c.normal.x * 0.5f + 0.5f, c.normal.y * 0.5f + 0.5f, c.normal.z * 0.5f + 0.5f); edepth = c.t; }
       }
     }
+#ifdef SVO_STAMPS
+    asm volatile("" ::"v"(ecol.x), "v"(ecol.y), "v"(ecol.z), "v"(edepth), "v"(io.x), "v"(d.x) : "memory");
+    st_r2 = __builtin_readcyclecounter();
+    {
+      // st_r1 is per lane (taken under the branch): the wave's figure = the largest (the lanes that took the branch share one clock read)
+      unsigned long long m = st_r1;
+      for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(m, o, 64); m = x > m ? x : m; }
+      if (m != 0) { st_part[0] += m - st_t0; st_part[1] += st_r2 - m; }
+    }
+#endif
     if (emit) persist_emit(a, pix, seg >> 8, px, py, ecol, edepth);
 
 #ifdef SVO_STAMPS
-    st_shade += __builtin_readcyclecounter() - st_t0;
+    { const unsigned long long now = __builtin_readcyclecounter(); st_shade += now - st_t0; st_part[2] += now - st_r2; st_r2 = now; }
 #endif
     // ---------------- refill idle lanes: ballot + prefix count, one atomic per wave
     // (a wave whose band is used up tries the next band in its next round; SVO_STEAL_NOW=1 tries it in the same round:
@@ -473,8 +500,10 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             si = r / gsize;
             j = (int)(first + r % gsize);
           }
+#if SVO_PICK
           // the pick pixel's tile changes places with the band's first one
           if ((int)band == a.pick_band) j = j == 0 ? a.pick_j : (j == a.pick_j ? 0 : j);
+#endif
           int tile_x = (int)udiv_by((uint32_t)j, (uint32_t)band_rows, a.mg_rows[full_band]);
           const int tile_y = first_row + (j - tile_x * band_rows);
           if (a.reverse) tile_x = f.tiles_x - 1 - tile_x;   // serpentine: this frame ends where the next one starts
@@ -554,6 +583,12 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
         }
       }
     }
+#ifdef SVO_STAMPS
+    asm volatile("" ::"v"(d.x), "v"(r), "v"(pix) : "memory");
+    { const unsigned long long now = __builtin_readcyclecounter(); st_part[3] += now - st_r2; st_r2 = now; }
+    st_lanes_init += (unsigned long long)__builtin_popcountll(__ballot(ninit));
+    st_lanes_refilled += (unsigned long long)__builtin_popcountll(__ballot(ninit && !icone && (seg & 0xffu) == 0u));
+#endif
     // ---------------- set up the new rays: regenerated bounce / shadow rays and refilled primaries together
     if (ninit) {
       status = walk.init(t, io, d, icone, its);
@@ -566,7 +601,7 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
     }
 
 #ifdef SVO_STAMPS
-    { const unsigned long long now = __builtin_readcyclecounter(); st_round += now - st_t0; st_t0 = now; st_nround++; }
+    { const unsigned long long now = __builtin_readcyclecounter(); st_part[4] += now - st_r2; st_round += now - st_t0; st_t0 = now; st_nround++; }
 #endif
     // ---------------- traverse until enough lanes have stopped to make a round worthwhile
     const int active0 = __builtin_popcountll(__ballot(status == ST_ACTIVE));
@@ -601,6 +636,12 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
 
   }
   atomicAdd(a.heads + 8 * kHeadStride + 32 + lane, st_mix[8]);
+  atomicAdd(a.heads + 8 * kHeadStride + 32 + 64 + lane, st_mix[9]);
+  if (lane == 0u) {
+    unsigned long long *parts = (unsigned long long *)(a.heads + 8 * kHeadStride + 32 + 64 + 64);
+    for (int i = 0; i < 5; i++) atomicAdd(parts + i, st_part[i]);
+    atomicAdd(parts + 5, st_lanes_shaded); atomicAdd(parts + 6, st_lanes_init); atomicAdd(parts + 7, st_lanes_refilled);
+  }
   if (lane == 0u) {
     unsigned long long *dbg = (unsigned long long *)(a.heads + 8 * kHeadStride);
     atomicAdd(dbg + 0, st_round); atomicAdd(dbg + 1, st_trav); atomicAdd(dbg + 2, st_nround); atomicAdd(dbg + 3, st_ntrip); atomicAdd(dbg + 4, st_shade); atomicAdd(dbg + 5, st_load);
@@ -721,8 +762,12 @@ __global__ __launch_bounds__(SVO_RC_BLOCK) void rc_table_kernel(const Frame f, F
   }
 }
 
-// the spare-ray kernel (svo_persist2.hip.h, included behind this file by svo_hip.hip)
-#if SVO_ASM_LOOP
+// the spare-ray kernel (svo_persist2.hip.h, included behind this file by svo_hip.hip in SVO_VARIANTS builds)
+#ifndef SVO_VARIANTS
+#define SVO_VARIANTS 0
+#endif
+#define SVO_HAVE_SPARE (SVO_ASM_LOOP && SVO_VARIANTS)
+#if SVO_HAVE_SPARE
 template <int kMode>
 inline void persist2_launch_mode(const PersistArgs &a, int blocks, hipStream_t stream);
 inline hipError_t persist2_occupancy(int *per_cu);
@@ -739,7 +784,7 @@ inline hipError_t persist2_occupancy(int *per_cu);
 
 template <int kMode>
 inline void persist_launch_mode(const PersistArgs &a, int blocks, hipStream_t stream) {
-#if SVO_ASM_LOOP
+#if SVO_HAVE_SPARE
   if (a.spare) { persist2_launch_mode<kMode>(a, blocks, stream); return; }
 #endif
   if (a.rc && a.desc) {   // (the tables are only made for launches that walk the descriptor table)
@@ -799,7 +844,11 @@ __global__ __launch_bounds__(64) void persist_resolve_sequence_kernel(const Fram
 inline bool persist_can_fold(const Frame &f, int n) {
   const unsigned long long nb = (unsigned long long)(f.batch > 1 ? f.batch : 1);
   const unsigned long long bytes = 192ull * (unsigned long long)n * (unsigned long long)f.ntiles * nb * sizeof(float);
+#if SVO_VARIANTS
   static const unsigned long long budget = getenv("SVO_FOLD_BYTES") ? strtoull(getenv("SVO_FOLD_BYTES"), nullptr, 10) : (4ull << 30);
+#else
+  const unsigned long long budget = 4ull << 30;
+#endif
   return SVO_BAND_COLMAJOR && n > 1 && f.bounces <= 255 && bytes <= budget && f.batch <= 255 && n < 65536 &&
          (long long)f.ntiles * (long long)nb * n < (1ll << 25);
 }
@@ -833,17 +882,19 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
       per_cu = 16;
     b.max_per_cu_desc = per_cu;
     b.cus = cus;
-    // experiment knobs (override svo_set_tuning)
+#if SVO_VARIANTS
+    // experiment knobs (override svo_set_tuning): libsvohip_variants.so only
     if (const char *e1 = getenv("SVO_PERSIST_WAVES_PER_CU")) b.waves_per_cu = atoi(e1);
     if (const char *e2 = getenv("SVO_PERSIST_THRESH")) b.thresh_num = atoi(e2);
     if (const char *e3 = getenv("SVO_SPARE")) b.spare_mode = atoi(e3) != 0 ? 1 : 0;
     if (const char *e4 = getenv("SVO_RC_TABLE")) b.table_mode = atoi(e4) != 0 ? 1 : 0;
     if (const char *e5 = getenv("SVO_NORMAL_TABLE")) b.ntab_mode = atoi(e5) != 0 ? 1 : 0;
+#endif
   }
   // the spare-ray kernel walks the descriptor table in assembly: pools the table cannot state, and builds with hipcc's
   // translation of the loop (SVO_ASM_LOOP=0), run persist_kernel
-  const bool spare_kernel = SVO_ASM_LOOP && b.spare_mode != 0 && desc != nullptr;
-#if SVO_ASM_LOOP
+  const bool spare_kernel = SVO_HAVE_SPARE && b.spare_mode != 0 && desc != nullptr;
+#if SVO_HAVE_SPARE
   if (spare_kernel && b.max_per_cu_spare == 0) {
     int per_cu = 0;
     if (persist2_occupancy(&per_cu) != hipSuccess || per_cu < 1) per_cu = 16;
@@ -954,7 +1005,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   // the pick: only launches that store pixels straight to rgba8 (one sample, no accumulation, one frame) over a whole frame
   a.pick_mail = nullptr; a.pick_pix = 0u; a.pick_seq = 0u; a.pick_band = -1; a.pick_j = 0;
   b.pick_carried = false;
-  const bool pick_ok = b.pick.mail != nullptr && spp == 1 && !f.progressive && fold == 1 && f.batch <= 1 && f.row_step == 1 && f.y0 == 0 &&
+  const bool pick_ok = SVO_PICK && b.pick.mail != nullptr && spp == 1 && !f.progressive && fold == 1 && f.batch <= 1 && f.row_step == 1 && f.y0 == 0 &&
                        f.out_y0 == 0 && f.y1 >= f.height && !spare_kernel && b.pick.x >= 0 && b.pick.x < f.width && b.pick.y >= 0 && b.pick.y < f.height &&
                        SVO_BAND_COLMAJOR;
   for (int s = 0; s < (fold > 1 ? 1 : spp); s++) {

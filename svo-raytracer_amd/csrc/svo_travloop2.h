@@ -77,8 +77,15 @@ namespace svo {
   "v_cmp_eq_u32 vcc, %[cnt], %[lane]\n\t"              \
   "v_addc_co_u32 %[hist], vcc, 0, %[hist], vcc\n\t"    \
   "s_mov_b64 exec, %[act]\n\t"
+// ... and a second histogram: lanes in the POP section of the trips that run it (round 6: sizing a deferred POP)
+#define SVO_HIST_POP                                    \
+  "s_mov_b64 exec, -1\n\t"                             \
+  "v_cmp_eq_u32 vcc, %[cnt], %[lane]\n\t"              \
+  "v_addc_co_u32 %[hist2], vcc, 0, %[hist2], vcc\n\t"  \
+  "s_mov_b64 exec, %[sp]\n\t"
 #else
 #define SVO_HIST
+#define SVO_HIST_POP
 #endif
 
 // Where a level's stack entry lives.  The descriptor table only exists for pools of at most 13 levels (svo_derive.hip.h), so
@@ -86,6 +93,10 @@ namespace svo {
 // level, identically in all pipelines) is dead here: the entry of scale s is at lds8 + (s - 11) * 512 = s * 512 + (lds8 - 11 * 512),
 // one shift-add on the scale instead of subtract, clamp, shift-add.  A POP that leaves the octree (scale 23: MISS) reads one row
 // past the column -- a row of the same wave's array or past it, where LDS reads return zero -- and drops what it read.
+// A PUSH below scale 11 (only from the phantom state behind a POP to a never-pushed level: no input produces one)
+// forms an address below the lane's column = below LDS offset 0: the hardware drops the write, a POP there reads zero.  That
+// needs the stack to be the kernel's ONLY __shared__ object, at offset 0: tests/test_kernel_isa.py checks the code object's LDS
+// size (6 144 bytes, not a byte more) for every descriptor-walk kernel.
 // SVO_STACK_CLAMP=1 builds the clamped form (A/B).
 #ifndef SVO_STACK_CLAMP
 #define SVO_STACK_CLAMP 0
@@ -185,6 +196,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
   uint32_t c0 = SVO_RFL(0), c1 = SVO_RFL(1), c2 = SVO_RFL(2), c3 = SVO_RFL(3), c4 = SVO_RFL(4), c5 = SVO_RFL(5), c6 = SVO_RFL(6), c7 = SVO_RFL(7);
 #undef SVO_RFL
   uint32_t hist = mix[8];   // lane L: trips of this wave that ran with exactly L lanes traversing
+  uint32_t hist2 = mix[9];  // lane L: trips of this wave whose POP section ran for exactly L lanes
 #else
   (void)mix;
 #endif
@@ -299,6 +311,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       "s_mov_b64 exec, %[sp]\n\t"                         // left the parent: POP
       "s_cbranch_execz LnoA%=\n\t"
       SVO_COUNT("c6", "c7", "exec")
+      SVO_HIST_POP
       // ---- POP (svotrace.comp:341-366)
       "v_ffbh_u32 %[t0], %[t0]\n\t"                       // (the differing bits of a POP lane are never zero: d >> scale > 1)
       SVO_POP_ADDR
@@ -346,7 +359,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
         [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd), [se] "=&s"(se), [sf] "=&s"(sf), [sg] "=&s"(sg), [sh] "=&s"(sh),
         [sp] "=&s"(sp), [sm] "=&s"(sm), [sx] "=&s"(sx), [cnt] "=&s"(cnt)
 #ifdef SVO_STAMPS
-        , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7), [hist] "+v"(hist)
+        , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3), [c4] "+s"(c4), [c5] "+s"(c5), [c6] "+s"(c6), [c7] "+s"(c7), [hist] "+v"(hist), [hist2] "+v"(hist2)
 #endif
       : [cx] "v"(r.cx), [bx] "v"(r.bx),
         [cy] "v"(r.cyz.x), [cz] "v"(r.cyz.y), [by] "v"(r.byz.x), [bz] "v"(r.byz.y), [oct] "v"(r.octant), [k005] "s"(0.05f), [conem] "s"(cone_lanes),
@@ -357,7 +370,7 @@ __device__ __forceinline__ void trav_loop2(const DescTab &tab, WaveStack2 &stk, 
       : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
   r.iter += kMaxIter + 1u;
 #ifdef SVO_STAMPS
-  mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7; mix[8] = hist;
+  mix[0] = c0; mix[1] = c1; mix[2] = c2; mix[3] = c3; mix[4] = c4; mix[5] = c5; mix[6] = c6; mix[7] = c7; mix[8] = hist; mix[9] = hist2;
 #endif
 }
 

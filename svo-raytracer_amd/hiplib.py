@@ -13,9 +13,9 @@ HIT_DTYPE = np.dtype([("pointer", "<u4"), ("raw_normal", "<u2"), ("value", "u1")
                       ("iter", "<u4"), ("t", "<f4")])
 
 EXPORTS = [
-    "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
+    "svo_build_info", "svo_create", "svo_destroy", "svo_last_error", "svo_pool_upload", "svo_pool_update", "svo_pool_download",
     "svo_pool_reserve", "svo_pool_upload_device", "svo_pool_device_ptr", "svo_build_from_heightmap", "svo_build_from_voxels", "svo_bind_outputs", "svo_set_camera", "svo_set_params", "svo_resize", "svo_set_rows", "svo_set_stripes",
-    "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_set_batch", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_count_frame",
+    "svo_set_pipeline", "svo_set_tuning", "svo_set_hit_records", "svo_set_progressive", "svo_set_batch", "svo_dispatch", "svo_dispatch_async", "svo_sync", "svo_set_pick", "svo_set_overlap", "svo_pick_info", "svo_count_frame",
     "svo_get_stats", "svo_set_stream", "svo_time_frames", "svo_read_color", "svo_read_depth", "svo_read_hits", "svo_read_pixel", "svo_read_beam",
     "svo_output_device_ptrs", "svo_set_derived", "svo_derived_info", "svo_derived_refresh_info",
     "svo_ring_create", "svo_ring_destroy", "svo_ring_submit", "svo_ring_wait", "svo_ring_query", "svo_ring_read_color",
@@ -44,6 +44,10 @@ class Stats(ctypes.Structure):
 # the same library built with hipcc's translation of the traversal loop instead of the assembly one
 # (csrc/Makefile target `cxxloop`); only the cross-check test loads it
 CXXLOOP_LIB_PATH = os.path.join(_HERE, "csrc", "libsvohip_cxxloop.so")
+# the product library's sources with the comparators and A/B switches built in (csrc/Makefile target `variants`): pipeline 2
+# (staged wavefront tracing), round 5's spare-ray kernel (SVO_SPARE=1) and the SVO_* environment switches.  Loaded by the tests
+# that compare against them (tests/helpers.py::DualContext) and by the tools/ A/B scripts; a host loads libsvohip.so.
+VARIANTS_LIB_PATH = os.path.join(_HERE, "csrc", "libsvohip_variants.so")
 
 _libs = {}
 
@@ -111,11 +115,14 @@ def lib(path=None):
         L.svo_set_derived.argtypes = [vp, ci]
         L.svo_derived_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ci), fp]
         L.svo_derived_refresh_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), fp]
+        L.svo_build_info.argtypes = []
         L.svo_dispatch.argtypes = [vp]
         L.svo_dispatch_async.argtypes = [vp]
         L.svo_sync.argtypes = [vp]
         L.svo_set_pick.argtypes = [vp, ctypes.c_int, ctypes.c_int]
         L.svo_set_overlap.argtypes = [vp, ctypes.c_int]
+        L.svo_pick_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64),
+                                    ctypes.POINTER(ctypes.c_uint64)]
         L.svo_count_frame.argtypes = [vp, ctypes.POINTER(Stats)]
         L.svo_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
         L.svo_set_stream.argtypes = [vp, vp]
@@ -552,6 +559,11 @@ class HipContext:
     def set_pick(self, x, y):
         """the pixel read_pixel answers without waiting for its frame (default: the image centre); x < 0: none"""
         self._chk(self._L.svo_set_pick(self._h, int(x), int(y)))
+
+    def pick_info(self):
+        x, y, m, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._chk(self._L.svo_pick_info(self._h, ctypes.byref(x), ctypes.byref(y), ctypes.byref(m), ctypes.byref(w)))
+        return {"x": x.value, "y": y.value, "from_mail": int(m.value), "waited": int(w.value)}
 
     def set_overlap(self, on):
         """dispatch_async alternates two {stream, image} sets (default on)"""

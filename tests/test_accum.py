@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import helpers
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "accum_golden.npz")
 PIPELINES = [int(v) for v in os.environ.get("SVO_TEST_PIPELINES", "0,1,2").split(",")]
@@ -44,7 +45,7 @@ def test_hip_accumulation_matches_the_reference_shader(seq, pipeline):
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
     pool, _ = scene.build_scene(seq["n"])
-    c = hiplib.HipContext(0)              # fresh context = cleared images, like fresh GL textures
+    c = helpers.DualContext()              # fresh context = cleared images, like fresh GL textures
     try:
         c.set_pipeline(pipeline)
         c.set_progressive(True)
@@ -80,7 +81,7 @@ def test_hip_accumulation_with_samples_stripes_and_beam_matches_oracle(pipeline)
     from oracle import oracle
     pool, _ = scene.build_scene(256)
     w, h, world = 120, 84, 2
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     try:
         c.set_pipeline(pipeline)
         c.set_progressive(True)
@@ -127,7 +128,7 @@ def test_hip_sequences_in_one_dispatch_match_the_reference_shader(seq, pipeline)
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
     pool, _ = scene.build_scene(seq["n"])
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     try:
         c.set_pipeline(pipeline)
         c.set_progressive(True)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from helpers import compare_with_golden, golden_case, golden_cases
+import helpers
 
 PIPELINES = [int(v) for v in os.environ.get("SVO_TEST_PIPELINES", "0,1,2").split(",")]
 
@@ -70,7 +71,7 @@ def test_beam_falls_back_on_cameras_that_are_not_a_planar_rectangle():
 @pytest.fixture(scope="module")
 def ctx():
     from svo_raytracer_amd import hiplib
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     yield c
     c.close()
 

@@ -43,6 +43,8 @@ def test_first_rung_fails_second_is_printed_with_its_history(capsys):
         seen.append(cmd)
         ex = cmd[cmd.index("--exchange") + 1]
         drv = cmd[cmd.index("--driver") + 1]
+        # the copy rung keeps its control plane off RCCL (what failed the rung before it may be RCCL itself)
+        assert env.get("SVO_BENCH_BACKEND", "") == ("gloo" if (drv, ex) == ("torch", "copy") else "")
         if (drv, ex) == ("torch", "rccl"):
             return 1, None, "RuntimeError: NCCL error: unhandled system error"
         return 0, {"metric": "m", "value": 123.0, "n_gpus": 8, "verified": True, "driver": drv, "exchange": ex, "fallback_from": []}, ""
@@ -135,7 +137,9 @@ def test_ranks_under_a_launcher_keep_the_rccl_gather_when_every_probe_is_clean(t
     res, port = _negotiate(tmp_path, fail_on=set())
     for r in res:
         assert (r["exchange"], r["backend"], r["tried"]) == ("rccl", "nccl", []) and r["initialized"] is False
-        assert r["seen"] == [["rccl", str(port + 101), "", "1", "0"]]       # a rendezvous of its own, no probing inside the probe
+        assert [r["seen"][0][0]] + r["seen"][0][2:] == ["rccl", "", "1", "0"] and len(r["seen"]) == 1   # no probing inside the probe
+    # a rendezvous of its own: a free port rank 0 picked, carried to every rank by the gloo group -- not the launcher's
+    assert res[0]["seen"][0][1] == res[1]["seen"][0][1] != str(port)
 
 
 def test_one_rank_s_probe_hangs_and_all_ranks_agree_on_the_copy_exchange(tmp_path):
@@ -143,7 +147,8 @@ def test_one_rank_s_probe_hangs_and_all_ranks_agree_on_the_copy_exchange(tmp_pat
     for rank, r in enumerate(res):
         assert (r["exchange"], r["backend"]) == ("copy", "gloo") and r["initialized"] is True    # the CPU group stays as control plane
         assert [t["exchange"] for t in r["tried"]] == ["rccl"] and r["tried"][0]["failed"].startswith("probe: ")
-        assert [s[0] for s in r["seen"]] == ["rccl", "copy"] and r["seen"][1][1:3] == [str(port + 102), "gloo"]
+        assert [s[0] for s in r["seen"]] == ["rccl", "copy"] and r["seen"][1][2] == "gloo"
+    assert res[0]["seen"][1][1] == res[1]["seen"][1][1] and res[0]["seen"][1][1] not in (str(port), res[0]["seen"][0][1])
     assert "timed out" in res[1]["tried"][0]["failed"] and "another rank" in res[0]["tried"][0]["failed"]
 
 

@@ -10,6 +10,7 @@ import os
 
 import numpy as np
 import pytest
+import helpers
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -59,7 +60,7 @@ def test_oracle_reproduces_the_reference_s_64_frame_accumulation(golden, pool):
 @pytest.fixture(scope="module")
 def ctx(pool):
     from svo_raytracer_amd import hiplib
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     c.pool_upload(pool)
     yield c
     c.close()

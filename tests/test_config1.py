@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import svo_raytracer_amd.scene as scene
+import helpers
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1_512.npz")
 CASES = [("K0", 1), ("K0", 3), ("K1", 1)]
@@ -50,7 +51,7 @@ def test_config1_hip_matches_reference(pool512, camname, mode, pipeline):
     from svo_raytracer_amd import hiplib
     z = np.load(GOLD)
     key = "%s_m%d" % (camname, mode)
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.set_pipeline(pipeline)
         _check(ctx.render(pool512, 256, 256, z[key + "/cam"], 2, mode), z, key)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import svo_raytracer_amd.scene as scene
+import helpers
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_8192.npz")
 
@@ -81,7 +82,7 @@ def test_config2_hip_matches_reference_at_full_size(pool2048, pipeline):
     from svo_raytracer_amd import hiplib
     z = np.load(GOLD)
     step = int(z["step"][0])
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.set_pipeline(pipeline)
         ctx.pool_upload(pool2048)
@@ -98,7 +99,7 @@ def test_config3_hip_matches_reference_at_full_size(pool8192, pipeline):
     from svo_raytracer_amd import hiplib
     z = np.load(GOLD)
     step = int(z["step"][0])
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.set_pipeline(pipeline)
         ctx.pool_upload(pool8192)
@@ -120,7 +121,7 @@ def test_config3_as_the_benchmark_runs_it(pool8192):
     z = np.load(GOLD)
     step = int(z["step"][0])
     w, h = 1920, 1080
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.set_pipeline(1)
         ctx.pool_upload(pool8192)

@@ -5,6 +5,7 @@ import pytest
 import fuzzpool
 import svo_raytracer_amd.scene as scene
 from svo_raytracer_amd.cameras import CAMERAS, rot_cam
+import helpers
 
 CAMS = [CAMERAS["K0"], CAMERAS["K1"], rot_cam((1.45, 1.7, 2.9), -0.35, 0.1), rot_cam((1.5, 1.5, 1.5), 0.9, 2.0)]
 
@@ -24,7 +25,7 @@ def test_fuzz_hip_matches_oracle(seed):
     pool = fuzzpool.random_pool(seed, max_depth=5 + seed % 2, p_interior=0.8, p_empty=0.8)
     if seed % 3 == 2:
         pool = scene.embed_deep(pool, 7)       # depth 12-13: LOD cap on bounce rays, Phong branch
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         for pipeline in (0, 1, 2):
             ctx.set_pipeline(pipeline)
@@ -99,7 +100,7 @@ def test_fuzz_mangled_pools_and_beam_match_oracle(seed):
     from svo_raytracer_amd import hiplib
     from oracle import oracle
     base = fuzzpool.random_pool(seed, max_depth=5, p_interior=0.8, p_empty=0.8)
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         for pool in (base, _mangled(base, seed)):
             for pipeline in (0, 1, 2):

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from helpers import compare_with_golden
+import helpers
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _Z = None
@@ -58,7 +59,7 @@ def test_oracle_matches_reference_shader_on_fuzz_pools(name, poolkey):
 @pytest.mark.parametrize("poolkey", sorted({pk for _, pk in _cases()}))
 def test_hip_matches_reference_shader_on_fuzz_pools(poolkey):
     from svo_raytracer_amd import hiplib
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         pool = _z()["pool/" + poolkey]
         names = [n for n, pk in _cases() if pk == poolkey]

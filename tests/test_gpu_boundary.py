@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +16,7 @@ PIPELINES = [int(v) for v in os.environ.get("SVO_TEST_PIPELINES", "0,1,2").split
 @pytest.fixture(scope="module")
 def ctx():
     from svo_raytracer_amd import hiplib
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     yield c
     c.close()
 
@@ -233,7 +234,7 @@ def test_config5_8192_1080p_64_samples_per_pixel():
     from svo_raytracer_amd.cameras import CAMERAS
     from oracle import oracle
     pool, _ = scene.build_scene(8192)
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     try:
         w, h, step = 1920, 1080, 32
         c.set_pipeline(1)

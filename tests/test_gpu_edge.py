@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +16,7 @@ PIPELINES = [int(v) for v in os.environ.get("SVO_TEST_PIPELINES", "0,1,2").split
 @pytest.fixture(scope="module")
 def ctx():
     from svo_raytracer_amd import hiplib
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     yield c
     c.close()
 

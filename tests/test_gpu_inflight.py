@@ -4,6 +4,7 @@ guarantees for that usage (include/svo_hip.h): per-frame counter sets and sample
 after the frame that used them has finished, and pool edits wait for every frame in flight."""
 import numpy as np
 import pytest
+import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     from svo_raytracer_amd import hiplib
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     yield c
     c.close()
 
@@ -422,7 +423,7 @@ import svo_raytracer_amd.scene as scene
 from svo_raytracer_amd import hiplib
 from svo_raytracer_amd.cameras import CAMERAS
 pool, _ = scene.build_scene(128)
-ctx = hiplib.HipContext(0)
+ctx = hiplib.HipContext(0, lib_path=hiplib.VARIANTS_LIB_PATH)     # (SVO_FOLD_BYTES is one of the variants library's switches)
 ctx.set_pipeline(1)
 out = {}
 for i, (w, h, spp, bounces, mirror, frame) in enumerate([(200, 120, 5, 3, 0, 4), (64, 37, 16, 2, 0b110, 9), (333, 50, 2, 2, 0, 2)]):

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import compare_with_golden, golden_case, golden_cases
+import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +17,7 @@ PIPELINES = [int(v) for v in os.environ.get("SVO_TEST_PIPELINES", "0,1,2").split
 @pytest.fixture(scope="module")
 def ctx():
     from svo_raytracer_amd import hiplib
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     yield c
     c.close()
 
@@ -246,7 +247,7 @@ def test_spp8_8192_1080p_the_library_s_own_reading_of_the_sample_loop(ctx, pool8
 def test_c_abi_error_behaviour():
     """Status codes instead of exceptions or prints (include/svo_hip.h conventions)."""
     from svo_raytracer_amd import hiplib
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     try:
         c.resize(64, 48)
         with pytest.raises(hiplib.SvoError) as e:

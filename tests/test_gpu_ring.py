@@ -2,6 +2,7 @@
 the frame a dispatch of its own renders; partial batches, slot re-use, caller-owned slots, stripes, errors."""
 import numpy as np
 import pytest
+import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -11,7 +12,7 @@ def ctx():
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd import hiplib
     from svo_raytracer_amd.cameras import CAMERAS
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     pool, _ = scene.build_scene(256)
     c.pool_upload(pool)
     c.set_camera(CAMERAS["K1"])
@@ -323,7 +324,7 @@ def test_hostile_cameras_as_frames_of_one_launch_match_the_reference_shader():
         w, h, frame, mode, same = (int(v) for v in z[name + "/meta"])
         path = tuple(int(v) for v in z[name + "/path"]) if name + "/path" in z.files else (2, 0)
         groups.setdefault((pk, w, h, mode, path), []).append((name, frame))
-    c = hiplib.HipContext(0)
+    c = helpers.DualContext()
     ncases = nlaunch = 0
     try:
         c.set_pipeline(1)

@@ -45,8 +45,9 @@ def test_spare_kernel_leaves_the_bytes_of_persist_kernel(monkeypatch):
     pool, _ = scene.build_scene(256)
     res = {}
     for spare in ("1", "0"):
-        monkeypatch.setenv("SVO_SPARE", spare)     # read by a context when it sets up its persistent pipeline
-        ctx = hiplib.HipContext(0)
+        monkeypatch.setenv("SVO_SPARE", spare)     # read by a context of libsvohip_variants.so when it sets up its persistent pipeline
+        # "1": the spare-ray kernel, which only the variants library carries; "0": the library that ships (it reads no such switch)
+        ctx = hiplib.HipContext(0, lib_path=hiplib.VARIANTS_LIB_PATH if spare == "1" else None)
         try:
             res[spare] = _frames(ctx, pool, CAMERAS)
         finally:
@@ -68,7 +69,7 @@ def test_spare_kernel_renders_the_reference_shader_s_config3_and_config4_frames(
     step = int(z["step"][0])
     pool, _ = scene.build_scene(8192)
     monkeypatch.setenv("SVO_SPARE", "1")
-    ctx = hiplib.HipContext(0)
+    ctx = hiplib.HipContext(0, lib_path=hiplib.VARIANTS_LIB_PATH)
     try:
         ctx.set_pipeline(1)
         ctx.pool_upload(pool)
@@ -122,7 +123,8 @@ def test_rounds_with_and_without_the_tables_leave_the_same_bytes(monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        ctx = hiplib.HipContext(0)
+        # "tables": the library that ships; "rounds": the variants library, which reads the two switches
+        ctx = hiplib.HipContext(0, lib_path=hiplib.VARIANTS_LIB_PATH if env else None)
         try:
             res[key] = programme(ctx)
         finally:

@@ -10,6 +10,7 @@ import sys
 
 import numpy as np
 import pytest
+import helpers
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 HOW = ("not produced yet: compile and run integration/java/tools/src/engine/DumpFixtures.java against the reference "
@@ -112,7 +113,7 @@ def test_numpy_builder_matches_the_reference_java():
 def test_gpu_builder_matches_the_reference_java():
     from svo_raytracer_amd import hiplib
     cases = build_cases()
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         for n, kind, seed, vox, pool in cases:
             nb = ctx.build_from_voxels(vox)
@@ -146,7 +147,7 @@ def test_brush_edited_java_pools_render_like_the_oracle():
     from svo_raytracer_amd.cameras import CAMERAS
     from oracle import oracle
     cases = brush_cases()
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         for pipeline in (0, 1):
             ctx.set_pipeline(pipeline)

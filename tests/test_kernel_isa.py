@@ -68,3 +68,28 @@ def test_persistent_kernels_use_no_scratch_beyond_the_known_spills(disassembly):
         ins = _kernel(disassembly, "persist_kernelILi0E", "DescWalkELb0ELb%dE" % tab)
         spills = sum(1 for i in ins if i.startswith("scratch_"))
         assert spills < 120, (tab, spills)
+
+
+def test_descriptor_walk_stack_is_the_kernel_s_only_lds_object(tmp_path):
+    """trav_loop2 forms a level's stack address from the scale alone (svo_travloop2.h: SVO_PUSH_ADDR / SVO_POP_ADDR without the
+    record walk's clamp): a push below level 12 -- only reachable from the phantom state behind a POP to a never-pushed level, which
+    no input produces -- lands below the lane's column, i.e. below LDS offset 0, and is dropped by the hardware, a pop there reads
+    zero.  That holds only while the stack is the kernel's SOLE shared object, starting at LDS offset 0: the code object must say
+    6 144 bytes of LDS (12 levels x 64 lanes x 8 bytes) for every descriptor-walk kernel, not a byte more."""
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(OBJDUMP) and os.path.exists(readelf)):
+        pytest.skip("llvm tools not installed")
+    so = shutil.copy(os.path.join(ROOT, "svo-raytracer_amd", "csrc", "libsvohip.so"), tmp_path)
+    subprocess.check_call([OBJDUMP, "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp_path)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    notes = subprocess.check_output([readelf, "--notes", os.path.join(tmp_path, co[0])], text=True)
+    lds, seen = None, 0
+    for line in notes.splitlines():
+        m = re.match(r"\s*\.group_segment_fixed_size:\s*(\d+)", line)
+        if m:
+            lds = int(m.group(1))
+        m = re.match(r"\s*\.name:\s*(\S+)", line)
+        if m and "persist_kernel" in m.group(1) and "DescWalk" in m.group(1):
+            assert lds == 12 * 64 * 8, (m.group(1), lds)
+            seen += 1
+    assert seen >= 20, seen

@@ -115,7 +115,7 @@ def test_oracle_matches_the_reference_shader_on_the_matrix_cells(big):
 @pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_hip_matches_the_reference_shader_on_the_caves_family(pipeline):
     from svo_raytracer_amd import hiplib
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.set_pipeline(pipeline)
         last = None
@@ -138,7 +138,7 @@ def test_hip_matches_the_reference_shader_on_the_matrix_cells(big):
     sk, pool = big
     z = Z()
     step = int(z["step"][0])
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.pool_upload(pool)
         for name in _full(sk):

@@ -9,6 +9,7 @@ from svo_raytracer_amd import hostlib
 from oracle import octree as restated
 import svo_raytracer_amd.scene as scene
 from svo_raytracer_amd.cameras import CAMERAS, rot_cam
+import helpers
 
 EDITS = [
     ("sphere", (20, 24, 40), 7, 2),     # add
@@ -81,7 +82,7 @@ def test_ranged_updates_render_like_a_full_upload(pipeline):
     pool, _ = scene.build_scene(64)
     o = hostlib.Octree(4096)
     o.adopt(pool)
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.set_pipeline(pipeline)
         ctx.pool_upload(pool)
@@ -118,7 +119,7 @@ def test_descriptor_table_follows_brush_strokes_without_a_rebuild():
     o.adopt(pool)
     rng = np.random.default_rng(11)
     cams = [KEDIT, CAMERAS["K1"]]
-    ctx = hiplib.HipContext(0)
+    ctx = helpers.DualContext()
     try:
         ctx.set_pipeline(1)
         ctx.set_derived(1)

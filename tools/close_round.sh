@@ -21,12 +21,13 @@ fi
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | line > $O/bench_driver_k20.json
 B="--cpu-seconds 0 --moving 0 --default-abi 0 --long-steps 0"
+V=$GRAFT_REPO_ROOT/svo-raytracer_amd/csrc/libsvohip_variants.so   # the comparators and the SVO_* switches live there
 python bench.py --inflight 1 --batch 1 $B 2>/dev/null | line > $O/bench_inflight1.json
 python bench.py --camera-path orbit $B 2>/dev/null | line > $O/bench_orbit.json
 python bench.py --camera-path orbit --inflight 1 --batch 1 $B 2>/dev/null | line > $O/bench_orbit_inflight1.json
-SVO_DERIVED=0 python bench.py $B 2>/dev/null | line > $O/bench_recordwalk.json
-SVO_SPARE=1 python bench.py $B 2>/dev/null | line > $O/bench_spare_kernel.json
-SVO_SPARE=1 python bench.py --inflight 1 --batch 1 $B 2>/dev/null | line > $O/bench_spare_kernel_inflight1.json
+SVO_HIP_LIB=$V SVO_DERIVED=0 python bench.py $B 2>/dev/null | line > $O/bench_recordwalk.json
+SVO_HIP_LIB=$V SVO_SPARE=1 python bench.py $B 2>/dev/null | line > $O/bench_spare_kernel.json
+SVO_HIP_LIB=$V SVO_SPARE=1 python bench.py --inflight 1 --batch 1 $B 2>/dev/null | line > $O/bench_spare_kernel_inflight1.json
 python bench.py --beam 1 $B 2>/dev/null | line > $O/bench_beam1.json
 python bench.py --mode 2 $B 2>/dev/null | line > $O/bench_mode2.json
 python bench.py --config C2 $B 2>/dev/null | line > $O/bench_C2.json

@@ -18,7 +18,7 @@ SCENES = {"t1a8": ("terrain", 1, 8), "t2a18": ("terrain", 2, 18), "c1a8d64": ("c
 SCENE_TEXT = {"t1a8": "terrain, seed 1, amplitude 8/16 (rounds 1-5)", "t2a18": "terrain, seed 2, amplitude 18/16",
               "c1a8d64": "caves: terrain seed 1 + hashed balls (dens 64/256)"}
 CAMS = ("K0", "K1", "K2")
-BENCH = ["--steps", "400", "--warmup", "24", "--long-steps", "0", "--moving", "0", "--default-abi", "0", "--by-camera", "0", "--cpu-seconds", "0"]
+BENCH = ["--steps", "400", "--warmup", "24", "--long-steps", "0", "--moving", "0", "--default-abi", "0", "--by-camera", "0", "--ref-loop", "1", "--cpu-seconds", "0"]
 
 
 def bench_args(cell):
@@ -55,7 +55,7 @@ def main():
         for rep in range(2):
             for w in (8, 10, 12):
                 for t in (8, 9, 10):
-                    j = run_bench(a.sweep, ["--waves", str(w), "--thresh", str(t), "--verify", "0" if rep else "1", "--isolated", "0"], env)
+                    j = run_bench(a.sweep, ["--waves", str(w), "--thresh", str(t), "--verify", "0" if rep else "1", "--isolated", "0", "--ref-loop", "0"], env)
                     rows.append((w, t, rep, j["value"] if j else None))
                     print(rows[-1], flush=True)
         with open(os.path.join(a.out, "sweep_%s.md" % a.sweep), "w") as f:

@@ -34,7 +34,7 @@ for wpc in [int(v) for v in os.environ.get("STAMPS_WAVES", "10,20").split(",")]:
         ms = [ctx.ring_query(sl)["gpu_ms"] / BATCH]
     else:
         ms = ctx.time_frames(2, 1)   # 3 launches -> ring slots k, k+1, k+2; read all, take the last launch's set
-    buf = np.zeros(96, dtype=np.uint32)
+    buf = np.zeros(176, dtype=np.uint32)
     L.svo_debug_heads(ctx._h, buf.ctypes.data)
     d = buf[0:12].view(np.uint64)
     nw = 256 * wpc
@@ -44,6 +44,21 @@ for wpc in [int(v) for v in os.environ.get("STAMPS_WAVES", "10,20").split(",")]:
     hist = buf[32:96].astype(np.float64)   # [L] = trips with exactly L lanes traversing (64 lanes: the rest)
     h64 = max(trips - hist.sum(), 0.0)
     full = np.concatenate([hist, [h64]])
+    pop_hist = buf[96:160].astype(np.float64)   # [L] = trips whose POP section ran for exactly L lanes (L >= 1)
+    pop = None
+    if trips and pop_hist.sum() > 0:
+        pfull = np.concatenate([[max(trips - pop_hist.sum(), 0.0)], pop_hist[1:]])   # [0] = trips without a POP lane
+        pc = np.cumsum(pfull) / trips
+        pop = {"trips_without_pop_pct": round(100 * pfull[0] / trips, 1), "trips_with_1_to_5_pop_lanes_pct": round(100 * (pc[5] - pc[0]), 1),
+               "trips_with_6_to_15_pct": round(100 * (pc[15] - pc[5]), 1), "trips_with_16_or_more_pct": round(100 * (1 - pc[15]), 1),
+               "mean_pop_lanes_when_it_runs": round(float((pfull[1:] * np.arange(1, 64)).sum() / max(pfull[1:].sum(), 1)), 1)}
+        print("  POP section: %s" % pop)
+    parts = buf[160:176].view(np.uint64).astype(np.float64)   # cycles of all rounds by part, then lanes shaded / set up / refilled
+    nr = max(float(d[2]), 1.0)
+    rparts = {"cast_result_cycles": round(parts[0] / nr), "shade_cycles": round(parts[1] / nr), "store_cycles": round(parts[2] / nr),
+              "refill_cycles": round(parts[3] / nr), "ray_setup_cycles": round(parts[4] / nr), "round_cycles": round(float(d[0]) / nr),
+              "lanes_shaded": round(parts[5] / nr, 1), "lanes_set_up": round(parts[6] / nr, 1), "lanes_refilled": round(parts[7] / nr, 1)}
+    print("  a round by part (cycles of the wave, per round):", rparts)
     if trips:
         lanes = np.arange(65)
         mean = (full * lanes).sum() / full.sum()
@@ -55,7 +70,7 @@ for wpc in [int(v) for v in os.environ.get("STAMPS_WAVES", "10,20").split(",")]:
             "trips_below_40_lanes_pct": round(100 * float(cum[39]), 2), "trips_with_all_64_pct": round(100 * float(full[64] / full.sum()), 2),
             "trips_per_wave": round(trips / nw, 1), "rounds_per_wave": round(float(d[2]) / nw, 1),
             "sections": {n: {"share_of_trips_pct": round(100.0 * t / max(trips, 1), 1), "mean_lanes": round(l / max(t, 1), 1)} for n, (t, l) in sect.items()},
-            "ms_per_frame": round(float(ms[-1]), 4), "cell": CELL,
+            "ms_per_frame": round(float(ms[-1]), 4), "cell": CELL, "pop_section": pop, "round_parts": rparts,
             "what": "SVO_STAMPS build of the same sources: per trip of the assembly loop, lanes traversing; %d persistent waves per CU, "
                     "%d frame(s) per launch, one launch at a time, 8192^3 %s seed %d amp %d / 1920x1080 / mode 0 / %s" % (wpc, BATCH, SCENE, SEED, AMP, CAMERA)}
         print("  histogram by 8 lanes:", " ".join("%.1f" % (100 * full[i:i + 8].sum() / full.sum()) for i in range(0, 64, 8)), "| 64: %.1f" % (100 * full[64] / full.sum()))
