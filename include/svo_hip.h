@@ -238,11 +238,12 @@ int svo_dispatch_async(svo_ctx *ctx);
  *     dispatched frame (GL's semantics: a read-back sees the last dispatch) and wait for it alone; svo_sync waits for both.
  *     svo_set_overlap(ctx, 0) turns the alternation off (one stream, one image set, as before round 6).
  *   - the pick pixel -- svo_set_pick(x, y); default the image centre, Main.java:139-141 -- is answered without waiting for its
- *     frame: its 8x8 tile is the first its screen band draws, and the lane that stores the pixel also writes {rgba8, depth, hit
- *     record} and the dispatch's sequence number to pinned host memory; svo_read_pixel at that position polls the word (no
- *     stream synchronisation, no copy).  Any other position, a frame that carried no pick (other pipelines, stripes / row bands,
- *     batches, accumulation, caller-owned outputs) or a negative x (= no pick) take the waiting path: same values either way
- *     (tests/test_gpu_pick.py). */
+ *     frame: in front of the frame's kernels a launch of ONE wave on a high-priority stream of its own walks that pixel's path
+ *     (the same device functions on the same values: the same bits) and writes {rgba8, depth, hit record} and the dispatch's
+ *     sequence number to pinned host memory; svo_read_pixel at that position polls the word (no stream synchronisation, no copy).
+ *     The frame's own kernels carry nothing for it.  Any other position, a frame that gets no pick launch (stripes / row bands,
+ *     batches, accumulation, several samples per pixel, the beam pre-pass) or a negative x (= no pick) take the waiting path:
+ *     same values either way (tests/test_gpu_pick.py). */
 int svo_set_pick(svo_ctx *ctx, int x, int y);
 int svo_set_overlap(svo_ctx *ctx, int enabled);
 /* the pick position in force (-1, -1: none) and how many svo_read_pixel calls were answered from the mail / by waiting for

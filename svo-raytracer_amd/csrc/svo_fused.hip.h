@@ -264,4 +264,39 @@ __global__ __launch_bounds__(64) void trace_fused_kernel(const uint8_t *__restri
   }
 }
 
+// The pick pixel of a frame (svo_set_pick; the crosshair read-back of Main.updateEarly, Main.java:132-146), by a launch of its
+// own: ONE lane walks the pixel's whole path -- the same device functions, on the same values, as every pipeline's kernels, so the
+// same bits (tests/test_gpu_pick.py) -- and writes {rgba8, depth, hit record}, then the dispatch's sequence number, to host memory
+// the device can write.  svo_read_pixel polls that word instead of waiting for the frame.  A launch of one wave on a stream of
+// its own: it needs ONE free wave slot, not the frame's turn on the GPU, and the frame's kernels carry nothing for it (a pick
+// inside persist_kernel -- its tile drawn first, the lane that stores the pixel writing the mail -- was built first and cost the
+// throughput configuration 1.4 % through eleven more spilled SGPRs: profiles/round6_experiments.txt).
+constexpr int kPickWords = 8;   // seq, rgba8, depth bits, 0, hit[4]
+constexpr int kPickSlots = 8;   // mail slots, one per dispatch, re-used round-robin
+__global__ __launch_bounds__(64) void pick_kernel(const uint8_t *__restrict__ pool_base, const Frame f, const int px, const int py,
+                                                   uint32_t *mail, const uint32_t seq) {
+  __shared__ WaveStack stk;
+  const uint32_t lane = threadIdx.x;
+  if (lane != 0u) return;
+  Pool pool;
+  pool.base = pool_base;
+  pool.len = f.pool_len;
+  Counters cnt = {0, 0, 0, 0, 0};
+  PathState ps;
+  ps.hit = false; ps.pointer = 0; ps.value = 0; ps.raw = 0; ps.level = 0; ps.iter = 0; ps.t = 0.0f;
+  V3 col;
+  float depth;
+  trace_sample<false>(pool, stk, lane, f, mk(f.cam[0], f.cam[1], f.cam[2]), primary_direction(f, px, py), (float)px, (float)py,
+                      (float)f.frame_number, ps, true, col, depth, cnt, 0.0f);
+  mail[1] = final_rgba8(f, px, py, col, nullptr);   // (one sample, no accumulation: the live shader's store, debug square included)
+  mail[2] = __float_as_uint(depth);
+  mail[3] = 0u;
+  mail[4] = ps.pointer;
+  mail[5] = (ps.raw & 0xffffu) | ((ps.value & 0xffu) << 16) | ((ps.level & 0xffu) << 24);
+  mail[6] = ps.iter;
+  mail[7] = __float_as_uint(ps.t);
+  __threadfence_system();
+  __hip_atomic_store(mail, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace svo

@@ -82,6 +82,7 @@ struct svo_ctx {
   int pick_x = -1, pick_y = -1;
   bool pick_default = true;    // follows the image centre (the crosshair, Main.java:139-141) until svo_set_pick names a pixel
   uint32_t *pick_mail = nullptr;   // kPickSlots x kPickWords words of host memory the device writes
+  hipStream_t pick_stream = nullptr;   // the pick launches' own stream (greatest priority), made on first use
   uint32_t pick_seq = 0;       // sequence number of the last dispatch that carried the pick
   uint64_t pick_from_mail = 0, pick_waited = 0;   // svo_read_pixel calls answered from the mail / by waiting for the frame (svo_pick_info)
   bool pick_live = false;      // the current set's last dispatch carried it (cleared by everything else that renders into the set)
@@ -240,6 +241,7 @@ int svo_destroy(svo_ctx *c) {
   for (void *p : c->ipc_opened) if (p) (void)hipIpcCloseMemHandle(p);
   for (void *p : c->dev_allocs) if (p) (void)hipFree(p);
   if (c->alt_stream) (void)hipStreamDestroy(c->alt_stream);
+  if (c->pick_stream) (void)hipStreamDestroy(c->pick_stream);
   if (c->pick_mail) (void)hipHostFree(c->pick_mail);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -877,27 +879,33 @@ static int launch_frame_kernels(svo_ctx *c, Frame &f, bool count, uint32_t *colo
   return SVO_OK;
 }
 
-// the frame's pick request: a mail slot of its own per dispatch (kPickSlots of them, round-robin)
-static int arm_pick(svo_ctx *c) {
-  c->pb.pick = PickRequest();
-  c->pb.pick_carried = false;
+// The frame's pick: a launch of ONE wave (pick_kernel, svo_fused.hip.h) on a high-priority stream of its own, in front of the
+// frame's kernels; a mail slot of its own per dispatch (kPickSlots of them, round-robin).  Frames the live shader's store
+// applies to: one sample per pixel, no cross-frame accumulation, no batch, no beam pre-pass (its start distances change the
+// iteration count of the hit record), the whole frame (a rank's stripes / a row band may not even contain the pixel).
+static int launch_pick(svo_ctx *c) {
   c->pick_live = false;
-  if (c->pick_x < 0 || c->pipeline != 1 || c->batch != 1 || c->external_outputs) return SVO_OK;
+  if (c->pick_x < 0 || c->batch != 1 || c->progressive || c->spp != 1 || c->use_beam || c->rows_set || c->n_tile_rows >= 0) return SVO_OK;
+  Frame f;
+  int rc = make_frame(c, f);
+  if (rc) return rc;
+  if (f.ntiles <= 0 || c->pick_x >= f.width || c->pick_y >= f.height) return SVO_OK;
   if (!c->pick_mail) {
     HIPCHK(c, hipHostMalloc((void **)&c->pick_mail, (size_t)kPickSlots * kPickWords * sizeof(uint32_t), hipHostMallocCoherent));
     memset(c->pick_mail, 0, (size_t)kPickSlots * kPickWords * sizeof(uint32_t));
   }
-  const uint32_t seq = c->pick_seq + 1u == 0u ? 1u : c->pick_seq + 1u;   // (0 = "nothing written yet")
-  c->pb.pick.mail = c->pick_mail + (size_t)(seq % (uint32_t)kPickSlots) * kPickWords;
-  c->pb.pick.x = c->pick_x; c->pb.pick.y = c->pick_y; c->pb.pick.seq = seq;
-  return SVO_OK;
-}
-static void pick_armed(svo_ctx *c, int rc) {
-  if (rc == SVO_OK && c->pb.pick.mail && c->pb.pick_carried) {
-    c->pick_seq = c->pb.pick.seq;
-    c->pick_live = true; c->pick_live_x = c->pb.pick.x; c->pick_live_y = c->pb.pick.y;
+  if (!c->pick_stream) {
+    int lo = 0, hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (hi = the greatest priority = the numerically lowest value)
+    HIPCHK(c, hipStreamCreateWithPriority(&c->pick_stream, hipStreamNonBlocking, hi));
   }
-  c->pb.pick = PickRequest();
+  const uint32_t seq = c->pick_seq + 1u == 0u ? 1u : c->pick_seq + 1u;   // (0 = "nothing written yet")
+  uint32_t *mail = c->pick_mail + (size_t)(seq % (uint32_t)kPickSlots) * kPickWords;
+  hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(64), 0, c->pick_stream, c->d_pool, f, c->pick_x, c->pick_y, mail, seq);
+  HIPCHK(c, hipGetLastError());
+  c->pick_seq = seq;
+  c->pick_live = true; c->pick_live_x = c->pick_x; c->pick_live_y = c->pick_y;
+  return SVO_OK;
 }
 
 int svo_dispatch_async(svo_ctx *c) {
@@ -922,11 +930,14 @@ int svo_dispatch_async(svo_ctx *c) {
     c->stream = alt ? c->alt_stream : c->own_stream;
     c->d_color = alt ? c->alt_color : c->own_color; c->d_depth = alt ? c->alt_depth : c->own_depth; c->d_hits = alt ? c->alt_hits : c->own_hits;
     c->alt_inflight = true;
+    c->pb.in_overlap = true;   // the launch shape of overlapping one-frame launches unless svo_set_tuning named one
   }
-  int rc = arm_pick(c);
-  if (rc) return rc;
-  rc = launch_frame(c, false);
-  pick_armed(c, rc);
+  int rc = launch_pick(c);
+  if (rc == SVO_OK) {
+    rc = launch_frame(c, false);
+    if (rc) c->pick_live = false;
+  }
+  c->pb.in_overlap = false;
   return rc;
 }
 
@@ -946,11 +957,10 @@ int svo_dispatch(svo_ctx *c) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  int rc = arm_pick(c);
+  int rc = launch_pick(c);
   if (rc) return rc;
   rc = launch_frame(c, false);
-  pick_armed(c, rc);
-  if (rc) return rc;
+  if (rc) { c->pick_live = false; return rc; }
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0;
@@ -1401,14 +1411,14 @@ int svo_read_pixel(svo_ctx *c, int x, int y, void *rgba8, float *depth, svo_hit 
   if (!c->d_color) return fail(c, SVO_E_INVALID, "readback before svo_resize");
   HIPCHK(c, hipSetDevice(c->device));
   if (c->pick_live && x == c->pick_live_x && y == c->pick_live_y && c->pick_mail && (!hit || (c->write_hits && c->d_hits))) {
-    // the pick pixel of the last dispatch: the lane that stored it has written (or will write) the mail slot -- no wait for
-    // the frame, no copy.  Should the stream run dry without the word (it cannot on a whole frame), the waiting path answers.
+    // the pick pixel of the last dispatch: its pick launch has written (or will write) the mail slot -- no wait for the frame,
+    // no copy.  Should the pick stream run dry without the word, the waiting path answers.
     volatile uint32_t *m = c->pick_mail + (size_t)(c->pick_seq % (uint32_t)kPickSlots) * kPickWords;
     bool got = false;
     for (unsigned spin = 0;; spin++) {
       if (__atomic_load_n((const uint32_t *)m, __ATOMIC_ACQUIRE) == c->pick_seq) { got = true; break; }
       if ((spin & 255u) == 255u) {
-        const hipError_t q = hipStreamQuery(c->stream);
+        const hipError_t q = hipStreamQuery(c->pick_stream);
         if (q == hipSuccess) { got = __atomic_load_n((const uint32_t *)m, __ATOMIC_ACQUIRE) == c->pick_seq; break; }
         if (q != hipErrorNotReady) return fail(c, SVO_E_HIP, std::string("svo_read_pixel: ") + hipGetErrorString(q));
       }

@@ -73,25 +73,6 @@ struct PersistArgs {
   const float *rc;
   uint32_t rc_stride;
   const float4 *ntab;   // unit normals by 16-bit code (svo_trav2.h), or null
-  // The pick pixel of the frame (svo_set_pick; the crosshair read-back of Main.java:132-146): its tile is the first one its band
-  // draws, and the lane that stores the pixel also writes {rgba8, depth, hit record} and then the dispatch's sequence number into
-  // host memory the device can write -- svo_read_pixel polls that word instead of waiting for the whole frame.
-  uint32_t *pick_mail;   // kPickWords words: seq, rgba8, depth bits, 0, hit[4]; null = this launch answers no pick
-  uint32_t pick_pix;     // index of the pick pixel in the output images
-  uint32_t pick_seq;
-  int pick_band, pick_j; // its tile: the band and the tile slot inside the band (after the launch's column direction)
-};
-#ifndef SVO_PICK
-#define SVO_PICK 1   // 0 (A/B only): the kernels carry no pick code; svo_read_pixel then always takes the waiting path
-#endif
-constexpr int kPickWords = 8;
-constexpr int kPickSlots = 8;   // mail slots, one per dispatch, re-used round-robin
-
-// what a launch should answer (set by the caller around persist_launch, like in_ring)
-struct PickRequest {
-  uint32_t *mail = nullptr;   // the slot (device-visible host memory); null = none
-  int x = 0, y = 0;
-  uint32_t seq = 0;
 };
 
 // n / d by multiply-high with m = ceil(2^32 / d) = (2^32 + e) / d, 0 <= e < d (made on the host, udiv_magic): with
@@ -124,19 +105,7 @@ __device__ __forceinline__ void persist_emit(const PersistArgs &a, uint32_t pix,
 #endif
   if (a.f.spp <= 1 && !a.f.progressive) {   // the live shader's case: straight to rgba8
     if (px < 10 && py < 10) col = a.f.dword0 == 0u ? mk(1.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
-    const uint32_t rgba = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
-    a.color[pix] = rgba;
-#if SVO_PICK
-    if (a.pick_mail != nullptr && pix == a.pick_pix) {   // one lane of one wave per frame
-      uint32_t *m = a.pick_mail;
-      m[1] = rgba; m[2] = __float_as_uint(depth); m[3] = 0u;
-      uint4 h = make_uint4(0u, 0u, 0u, 0u);
-      if (a.f.write_hits && a.hits != nullptr) h = a.hits[pix];   // this lane's own store of the primary cast
-      m[4] = h.x; m[5] = h.y; m[6] = h.z; m[7] = h.w;
-      __threadfence_system();
-      __hip_atomic_store(m, a.pick_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-#endif
+    a.color[pix] = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xff000000u;
   } else if (a.fold > 1) {
     // every sample in a slot of its own, [frame][tile][sample][channel][pixel of the tile]: the 64 values of a tile's
     // sample and channel share two cache lines, and the kernel that adds the samples up in order reads them coalesced
@@ -500,10 +469,6 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
             si = r / gsize;
             j = (int)(first + r % gsize);
           }
-#if SVO_PICK
-          // the pick pixel's tile changes places with the band's first one
-          if ((int)band == a.pick_band) j = j == 0 ? a.pick_j : (j == a.pick_j ? 0 : j);
-#endif
           int tile_x = (int)udiv_by((uint32_t)j, (uint32_t)band_rows, a.mg_rows[full_band]);
           const int tile_y = first_row + (j - tile_x * band_rows);
           if (a.reverse) tile_x = f.tiles_x - 1 - tile_x;   // serpentine: this frame ends where the next one starts
@@ -656,6 +621,10 @@ constexpr int kFoldGroup = 8;
 // waves take the CUs the previous launch's tail frees.  Swept in rounds 2-4 (profiles/round4_experiments.txt: 10 waves with
 // rounds at 9/16 is the shape every headline number was measured on; 16: -6 %).
 constexpr int kRingWavesPerCu = 10;
+// ... and when svo_dispatch_async alternates its two {stream, image} sets (the reference's loop, one frame per launch, the next
+// frame starting in this one's tail): 12 waves per CU and launch measured best -- 5 737 Mrays/s against 5 329 with launches that
+// fill the GPU (24), 5 658 at 16, 5 358 at 10 (tools/loop_shape.py, profiles/round6_experiments.txt)
+constexpr int kOverlapWavesPerCu = 12;
 constexpr int kHeadSets = 8;   // counter sets: one per frame in flight (its sample launches follow one another on one
                                // stream and share it), reused round-robin
 constexpr int kFaccSets = 4;   // colour-sum buffers (spp > 1): one per frame, reused round-robin
@@ -687,12 +656,11 @@ struct PersistBuffers {
   int waves_per_cu = 0;      // 0 = automatic: as many as fit (occupancy query) for one launch at a time, kRingWavesPerCu for
                              // the submissions of a ring with more than one slot (in_ring, set around the launch by ring_submit)
   bool in_ring = false;
+  bool in_overlap = false;   // set around the launch by svo_dispatch_async while it alternates its two sets
   int last_blocks = 0, last_per_cu = 0;   // shape of the last launch (svo_launch_info)
   int max_per_cu = 16, max_per_cu_desc = 16, cus = 256;   // resident waves per CU: byte walk / descriptor walk
   int max_per_cu_spare = 0;                               // ... / the spare-ray kernel (0 = not asked yet)
   int cus_reserved = 0;   // CUs the launching stream may not use (svo_set_reserved_cus): fewer persistent waves
-  PickRequest pick;       // the pick the next launch answers (svo_dispatch_async / svo_dispatch set it around the launch)
-  bool pick_carried = false;   // ... and whether that launch did carry it (whole frames, one sample per pixel, no batch)
   unsigned launches = 0, frames = 0;
 };
 
@@ -703,7 +671,6 @@ inline void persist_free(PersistBuffers &b) {
   for (auto &f : b.facc) if (f) (void)hipFree(f);
   for (auto &e : b.head_done) if (e) (void)hipEventDestroy(e);
   for (auto &e : b.facc_done) if (e) (void)hipEventDestroy(e);
-  b.pick = PickRequest();
   const int wpc = b.waves_per_cu, th = b.thresh_num, sm = b.spare_mode, tm = b.table_mode;   // tuning survives a resize
   const float4 *nt = b.ntab;
   const int nm = b.ntab_mode;
@@ -914,7 +881,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   }
   {
     const int fill = spare_kernel ? b.max_per_cu_spare : (desc ? b.max_per_cu_desc : b.max_per_cu);
-    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (b.in_ring ? std::min(kRingWavesPerCu, fill) : fill);
+    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (b.in_ring ? std::min(kRingWavesPerCu, fill) : (b.in_overlap ? std::min(kOverlapWavesPerCu, fill) : fill));
     b.blocks = (b.cus - b.cus_reserved) * per_cu;
     b.last_per_cu = per_cu;
   }
@@ -1002,24 +969,9 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
     a.rc = b.rc[hset]; a.rc_stride = (uint32_t)stride;
   }
   if (b.head_used[hset] && (e = hipStreamWaitEvent(stream, b.head_done[hset], 0)) != hipSuccess) return (int)e;
-  // the pick: only launches that store pixels straight to rgba8 (one sample, no accumulation, one frame) over a whole frame
-  a.pick_mail = nullptr; a.pick_pix = 0u; a.pick_seq = 0u; a.pick_band = -1; a.pick_j = 0;
-  b.pick_carried = false;
-  const bool pick_ok = SVO_PICK && b.pick.mail != nullptr && spp == 1 && !f.progressive && fold == 1 && f.batch <= 1 && f.row_step == 1 && f.y0 == 0 &&
-                       f.out_y0 == 0 && f.y1 >= f.height && !spare_kernel && b.pick.x >= 0 && b.pick.x < f.width && b.pick.y >= 0 && b.pick.y < f.height &&
-                       SVO_BAND_COLMAJOR;
   for (int s = 0; s < (fold > 1 ? 1 : spp); s++) {
     a.reverse = SVO_SERPENTINE ? (int)(b.launches++ & 1u) : 0;
     a.sample = s;
-    if (pick_ok) {
-      const int ty = b.pick.y >> 3, band = ty / a.rows_per_band, first_row = band * a.rows_per_band;
-      const int band_rows = std::min(a.rows_per_band, f.tiles_y - first_row);
-      const int tx = a.reverse ? f.tiles_x - 1 - (b.pick.x >> 3) : (b.pick.x >> 3);
-      a.pick_mail = b.pick.mail; a.pick_seq = b.pick.seq;
-      a.pick_pix = (uint32_t)b.pick.y * (uint32_t)f.width + (uint32_t)b.pick.x;
-      a.pick_band = band; a.pick_j = tx * band_rows + (ty - first_row);
-      b.pick_carried = true;
-    }
     const int nb = f.batch > 1 ? f.batch : 1;
     const bool packed = a.rc && fvar && fvar_host && nb <= kCamPack;
     if (fvar && !packed && s == 0 && copy_cams) { const int rcc = copy_cams(copy_arg); if (rcc) return rcc; }

@@ -308,8 +308,12 @@ class Renderer {
   void readFramebuffer(void *rgba8) { if (ensure()) check(svo_read_color(ctx, rgba8)); }
   void readDepth(float *d) { if (ensure()) check(svo_read_depth(ctx, d)); }
   void readHits(svo_hit *h) { if (ensure()) check(svo_read_hits(ctx, h)); }
-  // the crosshair pick of Main.updateEarly (Main.java:132-146) without the full-frame read-back; waits for the frame in flight
+  // the crosshair pick of Main.updateEarly (Main.java:132-146) without the full-frame read-back.  At the pick position
+  // (setPick; default the image centre = Main's crosshair) the value comes from pinned host memory as soon as the lane that
+  // renders the pixel has stored it -- the frame need not have ended (round 6); anywhere else it waits for the frame.
   float readDepthPixel(int x, int y) { float d = 0.0f; if (ensure()) check(svo_read_pixel(ctx, x, y, nullptr, &d, nullptr)); return d; }
+  void setPick(int x, int y) { if (ensure()) check(svo_set_pick(ctx, x, y)); }          // x < 0: no pick, every read-back waits
+  void setOverlap(bool on) { if (ensure()) check(svo_set_overlap(ctx, on ? 1 : 0)); }   // two {stream, image} sets in turn (default on)
   // dormant shader features (svotrace.comp:444, 500-504, 668-670); defaults = the live behaviour
   void setPathOptions(int bounces_, uint32_t mirrorMask_, int spp_) { bounces = bounces_; mirrorMask = mirrorMask_; spp = spp_; }
   svo_ctx *context() { ensure(); return ctx; }

@@ -86,25 +86,27 @@ def test_pick_positions_and_the_frames_that_carry_none(ctx):
             assert (got["hits"] == want["hits"]).all()
     with pytest.raises(Exception):
         ctx.set_pick(w, 0)
-    # frames that carry no pick answer through the waiting path -- same values
+    # frames that get no pick launch answer through the waiting path -- same values; the other pipelines' frames get one
+    # (pipeline 2 lives in the variants library: a context -- and counters -- of its own behind DualContext)
     ctx.set_pick(100, 60)
-    waited = ctx.pick_info()["waited"]
 
-    def waits(setup, undo):
-        nonlocal waited
+    def after(setup, undo, mail, wait, hits=True):
         setup()
+        i0 = ctx.pick_info()
         ctx.dispatch_async()
         px = ctx.read_pixel(100, 60)
-        waited += 1
-        assert ctx.pick_info()["waited"] == waited and ctx.pick_info()["from_mail"] == n_mail
+        i1 = ctx.pick_info()
+        assert (i1["from_mail"] - i0["from_mail"], i1["waited"] - i0["waited"]) == (mail, wait)
         undo()
-        return px
+        _pixel_matches(px, want, 100, 60, hits)
 
     for p in (0, 2):
-        _pixel_matches(waits(lambda: ctx.set_pipeline(p), lambda: ctx.set_pipeline(1)), want, 100, 60)
-    _pixel_matches(waits(lambda: ctx.set_pick(-1, -1), lambda: ctx.set_pick(100, 60)), want, 100, 60)
-    px = waits(lambda: ctx.set_rows(56, 72), lambda: ctx.resize(w + 8, h) or ctx.resize(w, h))     # a row band: no pick
-    _pixel_matches(px, want, 100, 60)
+        after(lambda: ctx.set_pipeline(p), lambda: ctx.set_pipeline(1), 1, 0)
+    after(lambda: ctx.set_pick(-1, -1), lambda: ctx.set_pick(100, 60), 0, 1)
+    after(lambda: ctx.set_rows(56, 72), lambda: ctx.resize(w + 8, h) or ctx.resize(w, h), 0, 1)      # a row band: no pick launch
+    after(lambda: ctx.set_params(2, 0, 0, 1, 2, 0, 1), lambda: ctx.set_params(2, 0, 0, 0, 2, 0, 1), 0, 1, hits=False)   # the beam pre-pass
+                                                                                   # (its frames differ in iteration counts only)
+    n_mail = ctx.pick_info()["from_mail"]
     ctx.set_pick(100, 60)
     # without hit records the pick still answers colour and depth from the mail
     ctx.set_hit_records(False)
@@ -223,3 +225,46 @@ def test_the_reference_loop_through_jni_typed_calls(ctx):
         assert nSetPick(j, -1, -1) == 0 and nSync(j) == 0
     finally:
         assert nDestroy(j) == 0
+
+
+def test_what_an_enqueued_dispatch_leaves_for_a_host_that_does_not_read_back(ctx):
+    """dispatchCompute of both host mirrors enqueues (svo_dispatch_async).  A host that looks at svo_get_stats or at the
+    device images right behind it, without a read-back, sees the frame only after svo_sync: last_dispatch_ms is the GPU time of
+    the last WAITING dispatch (svo_dispatch), never of an enqueued one, and svo_output_device_ptrs names the images of the last
+    dispatched frame -- which alternate between two sets while the library owns them."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd.cameras import CAMERAS
+    pool, _ = scene.build_scene(256)
+    w, h = 256, 144
+    ctx.pool_upload(pool)
+    ctx.resize(w, h)
+    ctx.set_camera(CAMERAS["K1"])
+    ctx.set_params(2, 0, 0, 0, 2, 0, 1)
+    ctx.dispatch()
+    t_wait = ctx.stats()["last_dispatch_ms"]
+    assert t_wait > 0
+    want = {}
+    for f in (3, 4, 5):
+        ctx.set_params(f, 0, 0, 0, 2, 0, 1)
+        ctx.dispatch()
+        want[f] = ctx.read_color()
+    t_wait = ctx.stats()["last_dispatch_ms"]
+    seen = []
+    for f in (3, 4, 5):
+        ctx.set_params(f, 0, 0, 0, 2, 0, 1)
+        ctx.dispatch_async()
+        assert ctx.stats()["last_dispatch_ms"] == t_wait          # not this frame's time: nothing waited for it
+        col_ptr = ctx.output_device_ptrs()[0]
+        seen.append(col_ptr)
+        ctx.sync()                                                # ... after which the device image is the frame
+        dev = ctx.dev_read(col_ptr, w * h * 4).reshape(h, w, 4)
+        assert (dev == want[f]).all(), f
+    assert seen[0] != seen[1] and seen[0] == seen[2]              # two image sets in turn
+    ctx.set_overlap(False)
+    ptrs = set()
+    for f in (3, 4):
+        ctx.set_params(f, 0, 0, 0, 2, 0, 1)
+        ctx.dispatch_async()
+        ptrs.add(ctx.output_device_ptrs()[0])
+    ctx.sync()
+    assert len(ptrs) == 1                                         # one set, as before round 6

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """The reference's loop (bench.py::run_reference_loop: nSetCamera, nSetParams, nDispatchAsync, nReadPixel at the crosshair, wall clock)
-by launch shape: persistent waves per CU of a dispatch (svo_set_tuning; 0 = the library's choice for one dispatch at a time: as many as
-fit).  GPU box only:  python tools/loop_shape.py [waves ...]   -> gpurun_out/loop_shape.txt"""
+by launch shape: persistent waves per CU of a dispatch (svo_set_tuning; 0 = the library's own choice: 12 while svo_dispatch_async alternates its two
+image sets, as many as fit -- 24 -- otherwise).  GPU box only:  python tools/loop_shape.py [waves ...]   -> gpurun_out/loop_shape.txt"""
 import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-shapes = [int(v) for v in sys.argv[1:]] or [0, 20, 16, 12, 10, 8]
+shapes = [int(v) for v in sys.argv[1:]] or [0, 24, 20, 16, 14, 12, 10]
 rows = []
 for rep in range(2):
     for w in shapes:
