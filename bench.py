@@ -784,7 +784,7 @@ def main(argv=None, ctx_factory=None):
     if args.seq > 1:
         batch = 1      # a step is a whole sequence: one submission, one image
     # The launch shape is the library's own (include/svo_hip.h, svo_set_tuning: a ring of several slots runs 10 persistent
-    # waves per CU and launch, rounds once 7/16 of the traversing lanes have stopped; one launch at a time fills the GPU):
+    # waves per CU and launch, a round once at most 9/16 of the lanes are still traversing; one launch at a time fills the GPU):
     # what a drop-in host gets without any call is what is measured here.  --waves / --thresh are experiment knobs.
     if args.pipeline == 1 and (args.waves >= 0 or args.thresh >= 0):
         ctx.set_tuning(max(args.waves, 0), max(args.thresh, 0))

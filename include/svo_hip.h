@@ -155,14 +155,16 @@ int svo_set_rows(svo_ctx *ctx, int y0, int y1);
 int svo_set_stripes(svo_ctx *ctx, int first_tile_row, int tile_row_step, int n_tile_rows, int out_row0);
 /* 0 = one thread per pixel (the reference's decomposition); 1 = persistent waves with lane
  * refill and in-place bounce regeneration; 2 = stage-per-kernel wavefront tracing with
- * compacted ray queues.  All three produce identical bytes; a new context runs pipeline 1 (the fast one). */
+ * compacted ray queues (a comparator: built into libsvohip_variants.so only; libsvohip.so refuses it with SVO_E_INVALID).
+ * All three produce identical bytes; a new context runs pipeline 1 (the fast one). */
 int svo_set_pipeline(svo_ctx *ctx, int pipeline);
-/* pipeline-1 launch shape: persistent waves per CU and the refill round threshold in sixteenths (0 = default 9: a round
- * starts once 7/16 of the traversing lanes have stopped).  waves_per_cu = 0 (what a new context has) = automatic: a
- * dispatch on the context's stream fills the GPU (right for one frame at a time); the submissions of a ring with more than
- * one slot (svo_ring_create / svo_group_ring_create) take 10 waves per CU and launch, so that the next launch's waves find
- * CU slots while the previous launch drains -- the shape bench.py's headline is measured on, without any call.  A
- * positive value is used as given everywhere (a caller that alternates its own streams with svo_set_stream: about 10). */
+/* pipeline-1 launch shape: persistent waves per CU and the round threshold in sixteenths (0 = default 9: a round starts once
+ * at most 9/16 of the lanes that were traversing at the start of the burst are still traversing).  waves_per_cu = 0 (what a
+ * new context has) = automatic: a waiting dispatch on the context's stream fills the GPU (24 per CU: right for one launch at a
+ * time); svo_dispatch_async while it alternates its two image sets takes 12 (two overlapping launches fill the GPU); the
+ * submissions of a ring with more than one slot (svo_ring_create / svo_group_ring_create) take 10 per launch, so that the next
+ * launch's waves find CU slots while the previous launch drains -- the shape bench.py's headline is measured on, without any
+ * call.  A positive value is used as given everywhere (a caller that alternates its own streams with svo_set_stream: ~10). */
 int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_sixteenths);
 /* shape of the last pipeline-1 launch of the context: persistent waves launched, waves per CU they were sized by, round
  * threshold in sixteenths (any pointer may be NULL).  Diagnostic: what svo_set_tuning's automatic choice resolved to. */

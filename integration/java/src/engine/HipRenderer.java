@@ -218,7 +218,7 @@ public class HipRenderer {
   /**
    * Create (or re-create) the ring; call after the first dispatchCompute / setImageSize has fixed the image size.  With more
    * than one slot the submissions run in the launch shape bench.py's headline is measured on (10 persistent waves per CU and
-   * launch, rounds at 9/16) by themselves -- no setTuning call needed; setTuning with a positive wave count overrides it.
+   * launch, a round once at most 9/16 of the lanes are still traversing) by themselves -- no setTuning call needed; setTuning with a positive wave count overrides it.
    */
   public void createFrameRing(int slots, int framesPerSlot, boolean wantHits) {
     check(nResize(ctx, width, height));

@@ -3,8 +3,9 @@
 // Each wave keeps 64 traversals in flight.  A lane owns one PATH at a time: its primary
 // ray, then -- regenerated in place from the hit -- its bounce / shadow ray(s); when the
 // path ends the lane stores the pixel and takes the next pixel of its XCD's screen band.
-// Finished lanes are handled in rounds: once 3/8 of the lanes that were traversing
-// have stopped, those lanes shade together (ballot), regenerate or retire, and the
+// Finished lanes are handled in rounds: once at most 9/16 of the lanes that were traversing
+// at the start of a burst of trips are still traversing (the default; svo_set_tuning), the
+// stopped lanes shade together (ballot), regenerate or retire, and the
 // freed lanes are refilled with one atomic per wave (ballot + prefix count).  Compared
 // with one-thread-per-pixel (pipeline 0 = the reference's decomposition) no lane waits for
 // the slowest ray of its tile; compared with stage-per-kernel wavefront tracing
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64, WalkWaves<Walk>::value) void persist_kernel(con
 constexpr int kFoldGroup = 8;
 // Persistent waves per CU and launch when several launches share the GPU (a ring of more than one slot): the next launch's
 // waves take the CUs the previous launch's tail frees.  Swept in rounds 2-4 (profiles/round4_experiments.txt: 10 waves with
-// rounds at 9/16 is the shape every headline number was measured on; 16: -6 %).
+// a round once at most 9/16 of the lanes are still traversing is the shape every headline number was measured on; 16 waves: -6 %).
 constexpr int kRingWavesPerCu = 10;
 // ... and when svo_dispatch_async alternates its two {stream, image} sets (the reference's loop, one frame per launch, the next
 // frame starting in this one's tail): 12 waves per CU and launch measured best -- 5 737 Mrays/s against 5 329 with launches that

@@ -21,7 +21,9 @@ def test_random_bursts_equal_synchronous_renders(seed):
     from svo_raytracer_amd.cameras import CAMERAS
     rng = np.random.RandomState(seed)
     pool, _ = scene.build_scene(512)
-    ctx = hiplib.HipContext(0)
+    # even seeds: the library that ships (pipelines 0 and 1); odd seeds: libsvohip_variants.so, where pipeline 2 joins the mix
+    other = [0, 2] if seed % 2 else [0, 0]
+    ctx = hiplib.HipContext(0, lib_path=hiplib.VARIANTS_LIB_PATH if seed % 2 else None)
     try:
         ctx.set_pipeline(1)
         sizes = [(320, 200), (203, 131)]
@@ -47,7 +49,7 @@ def test_random_bursts_equal_synchronous_renders(seed):
                 w, h = sizes[int(rng.randint(0, 2))]
                 ctx.resize(w, h)
             ctx.set_tuning(int(rng.choice([0, 3, 6, 10])), 9)
-            ctx.set_pipeline(int(rng.choice([1, 1, 1, 0, 2])))   # the burst's pipeline; the check below always uses pipeline 1
+            ctx.set_pipeline(int(rng.choice([1, 1, 1] + other)))   # the burst's pipeline; the check below always uses pipeline 1
             # ---- a burst of dispatches in flight
             nd = int(rng.randint(2, 7))
             plan, bufs = [], []
@@ -99,8 +101,9 @@ def test_random_ring_submissions_with_cameras_and_sequences(seed):
     from svo_raytracer_amd.cameras import CAMERAS, orbit_path
     rng = np.random.RandomState(seed)
     pool, _ = scene.build_scene(256)
-    ctx = hiplib.HipContext(0)
-    ref = hiplib.HipContext(0)       # the synchronous renderer: its own pool copy, table and images
+    other = [0, 2] if seed % 2 else [0, 0]     # (as above: odd seeds run on the variants library, with pipeline 2 in the mix)
+    ctx = hiplib.HipContext(0, lib_path=hiplib.VARIANTS_LIB_PATH if seed % 2 else None)
+    ref = hiplib.HipContext(0)       # the synchronous renderer (always the library that ships): its own pool copy, table and images
     try:
         w, h = 208, 136
         cur = pool.copy()
@@ -119,7 +122,7 @@ def test_random_ring_submissions_with_cameras_and_sequences(seed):
                     c.pool_update(cur, int(ptrs.min()), int(ptrs.max()) + 1)
             slots, per = int(rng.randint(1, 5)), int(rng.randint(1, 6))
             ctx.set_tuning(int(rng.choice([0, 4, 10])), 9)
-            ctx.set_pipeline(int(rng.choice([1, 1, 1, 0, 2])))
+            ctx.set_pipeline(int(rng.choice([1, 1, 1] + other)))
             ctx.ring_create(slots, per, want_hits=False)
             plan = []
             for d in range(slots + int(rng.randint(0, slots + 1))):      # some slots are re-used within the burst
