@@ -544,6 +544,8 @@ def run_reference_loop(pool, W, H, cam, args, nframes=300, warm=30):
         ok(nDerivedInfo(j, 0), "nDerivedInfo")
         if os.environ.get("SVO_LOOP_WAVES"):      # experiment knob (tools/loop_shape.py): the launch shape of the loop's dispatches
             ok(fn("nSetTuning", jint, jlong, jint, jint)(j, int(os.environ["SVO_LOOP_WAVES"]), int(os.environ.get("SVO_LOOP_THRESH", "0"))), "nSetTuning")
+        if os.environ.get("SVO_LOOP_SETS"):       # experiment knob: image sets svo_dispatch_async takes turns on (2 .. 4)
+            ok(nSetOverlap(j, int(os.environ["SVO_LOOP_SETS"])), "nSetOverlap")
         cx, cy = W // 2, H // 2
         one = np.zeros(1, np.float32)
         st = hiplib.Stats()

@@ -161,7 +161,7 @@ int svo_set_pipeline(svo_ctx *ctx, int pipeline);
 /* pipeline-1 launch shape: persistent waves per CU and the round threshold in sixteenths (0 = default 9: a round starts once
  * at most 9/16 of the lanes that were traversing at the start of the burst are still traversing).  waves_per_cu = 0 (what a
  * new context has) = automatic: a waiting dispatch on the context's stream fills the GPU (24 per CU: right for one launch at a
- * time); svo_dispatch_async while it alternates its two image sets takes 12 (two overlapping launches fill the GPU); the
+ * time); svo_dispatch_async while it takes turns on n image sets takes about 32 / n (4 sets: 8); the
  * submissions of a ring with more than one slot (svo_ring_create / svo_group_ring_create) take 10 per launch, so that the next
  * launch's waves find CU slots while the previous launch drains -- the shape bench.py's headline is measured on, without any
  * call.  A positive value is used as given everywhere (a caller that alternates its own streams with svo_set_stream: ~10). */
@@ -234,11 +234,12 @@ int svo_dispatch_async(svo_ctx *ctx);
 /* The reference's loop needs ONE pixel of frame N before it dispatches frame N + 1 (Main.updateEarly: the crosshair depth,
  * Main.java:132-146 -- there a glGetTexImage of the whole 8.3 MB depth image that waits for the frame; SURVEY T11 "where the
  * time goes today").  Here the two do not wait for each other:
- *   - svo_dispatch_async alternates TWO sets {stream, colour / depth / hit images} while the library owns both (no
+ *   - svo_dispatch_async takes turns on several sets {stream, colour / depth / hit images} while the library owns them (no
  *     svo_set_stream / svo_bind_outputs, pipeline 1, no cross-frame accumulation, no batch): frame N + 1's persistent waves take
  *     the CUs frame N's tail frees.  svo_read_color / _depth / _hits / _pixel and svo_output_device_ptrs always name the LAST
- *     dispatched frame (GL's semantics: a read-back sees the last dispatch) and wait for it alone; svo_sync waits for both.
- *     svo_set_overlap(ctx, 0) turns the alternation off (one stream, one image set, as before round 6).
+ *     dispatched frame (GL's semantics: a read-back sees the last dispatch) and wait for it alone; svo_sync waits for all.
+ *     svo_set_overlap(ctx, n): 0 = no alternation (one stream, one image set, as before round 6), 1 = the default (4 sets: up
+ *     to four frames in flight, like a swap chain), 2 .. 8 = that many sets.
  *   - the pick pixel -- svo_set_pick(x, y); default the image centre, Main.java:139-141 -- is answered without waiting for its
  *     frame: in front of the frame's kernels a launch of ONE wave on a high-priority stream of its own walks that pixel's path
  *     (the same device functions on the same values: the same bits) and writes {rgba8, depth, hit record} and the dispatch's

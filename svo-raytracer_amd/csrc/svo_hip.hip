@@ -69,15 +69,22 @@ struct svo_ctx {
   float *own_depth = nullptr;
   uint4 *own_hits = nullptr;
   // svo_dispatch_async alternates two sets {stream, images} while the library owns both (the reference's loop, Main.java:132-146,
-  // 257-289: frame N + 1 starts in frame N's tail): set 0 = own_stream + own_*, set 1 = alt_stream + alt_* (made on first use).
+  // 257-289: frame N + 1 starts in frame N's tail): set 0 = own_stream + own_*, sets 1 .. overlap - 1 = alt_* (made on first use).
   // c->stream / c->d_* always name ONE set, the one of the last dispatch, so every read-back sees the last dispatched frame.
-  hipStream_t alt_stream = nullptr;
-  uint32_t *alt_color = nullptr;
-  float *alt_depth = nullptr;
-  uint4 *alt_hits = nullptr;
+  static constexpr int kMaxSets = 8;
+  hipStream_t alt_stream[kMaxSets] = {};     // [0] unused: set 0 is own_stream / own_*
+  uint32_t *alt_color[kMaxSets] = {};
+  float *alt_depth[kMaxSets] = {};
+  uint4 *alt_hits[kMaxSets] = {};
   int cur_set = 0;
-  int overlap = 1;             // svo_set_overlap
-  bool alt_inflight = false;   // the set that is not current may still have a frame in flight
+  int overlap = 4;             // image sets svo_dispatch_async takes turns on (svo_set_overlap; 1 = no alternation)
+  bool alt_inflight = false;   // a set that is not current may still have a frame in flight
+  hipStream_t set_stream(int k) const { return k == 0 ? own_stream : alt_stream[k]; }
+  bool is_own_stream(hipStream_t st) const {
+    if (st == own_stream) return true;
+    for (int k = 1; k < kMaxSets; k++) if (alt_stream[k] && st == alt_stream[k]) return true;
+    return false;
+  }
   // the pick pixel (svo_set_pick): answered from pinned host memory by the lane that stores it
   int pick_x = -1, pick_y = -1;
   bool pick_default = true;    // follows the image centre (the crosshair, Main.java:139-141) until svo_set_pick names a pixel
@@ -205,11 +212,13 @@ static void free_outputs(svo_ctx *c) {
   if (c->own_depth) (void)hipFree(c->own_depth);
   if (c->own_hits) (void)hipFree(c->own_hits);
   c->own_color = nullptr; c->own_depth = nullptr; c->own_hits = nullptr;
-  if (c->alt_color) (void)hipFree(c->alt_color);
-  if (c->alt_depth) (void)hipFree(c->alt_depth);
-  if (c->alt_hits) (void)hipFree(c->alt_hits);
-  c->alt_color = nullptr; c->alt_depth = nullptr; c->alt_hits = nullptr;
-  if (c->cur_set == 1 && (c->stream == c->alt_stream || c->stream == nullptr)) c->stream = c->own_stream;
+  for (int k = 1; k < svo_ctx::kMaxSets; k++) {
+    if (c->alt_color[k]) (void)hipFree(c->alt_color[k]);
+    if (c->alt_depth[k]) (void)hipFree(c->alt_depth[k]);
+    if (c->alt_hits[k]) (void)hipFree(c->alt_hits[k]);
+    c->alt_color[k] = nullptr; c->alt_depth[k] = nullptr; c->alt_hits[k] = nullptr;
+  }
+  if (c->cur_set != 0 && (c->is_own_stream(c->stream) || c->stream == nullptr)) c->stream = c->own_stream;
   c->cur_set = 0; c->alt_inflight = false; c->pick_live = false;
   if (!c->external_outputs) { c->d_color = nullptr; c->d_depth = nullptr; c->d_hits = nullptr; }
 #if SVO_VARIANTS
@@ -240,7 +249,7 @@ int svo_destroy(svo_ctx *c) {
   ring_free(c);
   for (void *p : c->ipc_opened) if (p) (void)hipIpcCloseMemHandle(p);
   for (void *p : c->dev_allocs) if (p) (void)hipFree(p);
-  if (c->alt_stream) (void)hipStreamDestroy(c->alt_stream);
+  for (int k = 1; k < svo_ctx::kMaxSets; k++) if (c->alt_stream[k]) (void)hipStreamDestroy(c->alt_stream[k]);
   if (c->pick_stream) (void)hipStreamDestroy(c->pick_stream);
   if (c->pick_mail) (void)hipHostFree(c->pick_mail);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -512,8 +521,8 @@ int svo_bind_outputs(svo_ctx *c, void *color, void *depth, void *hits) {
   c->pick_live = false;
   if (!color) {
     c->external_outputs = false;
-    const bool alt = c->cur_set == 1 && c->alt_color;
-    c->d_color = alt ? c->alt_color : c->own_color; c->d_depth = alt ? c->alt_depth : c->own_depth; c->d_hits = alt ? c->alt_hits : c->own_hits;
+    const int k = (c->cur_set != 0 && c->alt_color[c->cur_set]) ? c->cur_set : 0;
+    c->d_color = k ? c->alt_color[k] : c->own_color; c->d_depth = k ? c->alt_depth[k] : c->own_depth; c->d_hits = k ? c->alt_hits[k] : c->own_hits;
     return SVO_OK;
   }
   if (!depth) return fail(c, SVO_E_INVALID, "svo_bind_outputs: depth buffer required");
@@ -636,14 +645,14 @@ int svo_set_stream(svo_ctx *c, void *hip_stream) {
   if (hip_stream) {
     // leaving the library's own streams: what they still have in flight writes the library's images, which dispatches on the
     // caller's stream may render into next
-    if (c->alt_inflight || c->stream == c->own_stream || c->stream == c->alt_stream) {
+    if (c->alt_inflight || c->is_own_stream(c->stream)) {
       HIPCHK(c, hipStreamSynchronize(c->own_stream));
-      if (c->alt_stream) HIPCHK(c, hipStreamSynchronize(c->alt_stream));
+      for (int k = 1; k < svo_ctx::kMaxSets; k++) if (c->alt_stream[k]) HIPCHK(c, hipStreamSynchronize(c->alt_stream[k]));
       c->alt_inflight = false;
     }
     c->stream = (hipStream_t)hip_stream;
   } else {
-    c->stream = (c->cur_set == 1 && c->alt_stream) ? c->alt_stream : c->own_stream;   // the current set's own
+    c->stream = (c->cur_set != 0 && c->alt_stream[c->cur_set]) ? c->alt_stream[c->cur_set] : c->own_stream;   // the current set's own
   }
   c->pick_live = false;
   return SVO_OK;
@@ -651,7 +660,9 @@ int svo_set_stream(svo_ctx *c, void *hip_stream) {
 
 int svo_set_overlap(svo_ctx *c, int enabled) {
   if (!c) return SVO_E_INVALID;
-  c->overlap = enabled ? 1 : 0;
+  // 0: one set (no alternation); 1: the default number of sets; 2 .. 4: that many
+  if (enabled < 0 || enabled > svo_ctx::kMaxSets) return fail(c, SVO_E_INVALID, "svo_set_overlap: 0 (off), 1 (the default number of sets) or 2 .. 8 sets");
+  c->overlap = enabled == 0 ? 1 : (enabled == 1 ? 4 : enabled);
   return SVO_OK;
 }
 
@@ -913,24 +924,27 @@ int svo_dispatch_async(svo_ctx *c) {
   HIPCHK(c, hipSetDevice(c->device));
   // Two sets {stream, images} in turn while the library owns both and nothing ties a frame to the image before it: the next
   // frame's persistent waves take the CUs this frame's tail frees (glDispatchCompute only enqueues as well: Renderer.java:118-121).
-  const bool own = !c->external_outputs && c->own_color && (c->stream == c->own_stream || (c->alt_stream && c->stream == c->alt_stream));
-  if (c->overlap && own && c->pipeline == 1 && !c->progressive && c->batch == 1) {
-    if (!c->alt_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking));
-    if (!c->alt_color) {
-      const size_t n = (size_t)c->width * (size_t)c->height;
-      HIPCHK(c, hipMalloc((void **)&c->alt_color, n * 4));
-      HIPCHK(c, hipMalloc((void **)&c->alt_depth, n * 4));
-      HIPCHK(c, hipMalloc((void **)&c->alt_hits, n * 16));
-      HIPCHK(c, hipMemsetAsync(c->alt_color, 0, n * 4, c->alt_stream));
-      HIPCHK(c, hipMemsetAsync(c->alt_depth, 0, n * 4, c->alt_stream));
-      HIPCHK(c, hipMemsetAsync(c->alt_hits, 0, n * 16, c->alt_stream));
+  const bool own = !c->external_outputs && c->own_color && c->is_own_stream(c->stream);
+  if (c->overlap > 1 && own && c->pipeline == 1 && !c->progressive && c->batch == 1) {
+    const int k = (c->cur_set + 1) % c->overlap;
+    if (k != 0) {
+      if (!c->alt_stream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->alt_stream[k], hipStreamNonBlocking));
+      if (!c->alt_color[k]) {
+        const size_t n = (size_t)c->width * (size_t)c->height;
+        HIPCHK(c, hipMalloc((void **)&c->alt_color[k], n * 4));
+        HIPCHK(c, hipMalloc((void **)&c->alt_depth[k], n * 4));
+        HIPCHK(c, hipMalloc((void **)&c->alt_hits[k], n * 16));
+        HIPCHK(c, hipMemsetAsync(c->alt_color[k], 0, n * 4, c->alt_stream[k]));
+        HIPCHK(c, hipMemsetAsync(c->alt_depth[k], 0, n * 4, c->alt_stream[k]));
+        HIPCHK(c, hipMemsetAsync(c->alt_hits[k], 0, n * 16, c->alt_stream[k]));
+      }
     }
-    c->cur_set ^= 1;
-    const bool alt = c->cur_set == 1;
-    c->stream = alt ? c->alt_stream : c->own_stream;
-    c->d_color = alt ? c->alt_color : c->own_color; c->d_depth = alt ? c->alt_depth : c->own_depth; c->d_hits = alt ? c->alt_hits : c->own_hits;
+    c->cur_set = k;
+    c->stream = c->set_stream(k);
+    c->d_color = k ? c->alt_color[k] : c->own_color; c->d_depth = k ? c->alt_depth[k] : c->own_depth; c->d_hits = k ? c->alt_hits[k] : c->own_hits;
     c->alt_inflight = true;
     c->pb.in_overlap = true;   // the launch shape of overlapping one-frame launches unless svo_set_tuning named one
+    c->pb.overlap_sets = c->overlap;
   }
   int rc = launch_pick(c);
   if (rc == SVO_OK) {
@@ -945,9 +959,9 @@ int svo_sync(svo_ctx *c) {
   if (!c) return SVO_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->alt_inflight) {   // the other set's frame too
+  if (c->alt_inflight) {   // the other sets' frames too
     HIPCHK(c, hipStreamSynchronize(c->own_stream));
-    if (c->alt_stream) HIPCHK(c, hipStreamSynchronize(c->alt_stream));
+    for (int k = 1; k < svo_ctx::kMaxSets; k++) if (c->alt_stream[k]) HIPCHK(c, hipStreamSynchronize(c->alt_stream[k]));
     c->alt_inflight = false;
   }
   return SVO_OK;

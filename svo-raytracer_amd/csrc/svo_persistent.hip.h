@@ -622,10 +622,10 @@ constexpr int kFoldGroup = 8;
 // waves take the CUs the previous launch's tail frees.  Swept in rounds 2-4 (profiles/round4_experiments.txt: 10 waves with
 // a round once at most 9/16 of the lanes are still traversing is the shape every headline number was measured on; 16 waves: -6 %).
 constexpr int kRingWavesPerCu = 10;
-// ... and when svo_dispatch_async alternates its two {stream, image} sets (the reference's loop, one frame per launch, the next
-// frame starting in this one's tail): 12 waves per CU and launch measured best -- 5 737 Mrays/s against 5 329 with launches that
-// fill the GPU (24), 5 658 at 16, 5 358 at 10 (tools/loop_shape.py, profiles/round6_experiments.txt)
-constexpr int kOverlapWavesPerCu = 12;
+// ... and when svo_dispatch_async takes turns on n {stream, image} sets (the reference's loop: one frame per launch, up to n
+// launches in flight): waves per CU and launch by n -- about 32 / n, the best of tools/loop_shape.py's sweeps
+// (profiles/round6_experiments.txt: 2 sets 12, 3 sets 10, 4 sets 8, 5 and more 6)
+inline int overlap_waves_per_cu(int sets) { return sets <= 2 ? 12 : sets == 3 ? 10 : sets == 4 ? 8 : 6; }
 constexpr int kHeadSets = 8;   // counter sets: one per frame in flight (its sample launches follow one another on one
                                // stream and share it), reused round-robin
 constexpr int kFaccSets = 4;   // colour-sum buffers (spp > 1): one per frame, reused round-robin
@@ -657,7 +657,8 @@ struct PersistBuffers {
   int waves_per_cu = 0;      // 0 = automatic: as many as fit (occupancy query) for one launch at a time, kRingWavesPerCu for
                              // the submissions of a ring with more than one slot (in_ring, set around the launch by ring_submit)
   bool in_ring = false;
-  bool in_overlap = false;   // set around the launch by svo_dispatch_async while it alternates its two sets
+  bool in_overlap = false;   // set around the launch by svo_dispatch_async while it takes turns on several image sets ...
+  int overlap_sets = 4;      // ... and on how many
   int last_blocks = 0, last_per_cu = 0;   // shape of the last launch (svo_launch_info)
   int max_per_cu = 16, max_per_cu_desc = 16, cus = 256;   // resident waves per CU: byte walk / descriptor walk
   int max_per_cu_spare = 0;                               // ... / the spare-ray kernel (0 = not asked yet)
@@ -882,7 +883,7 @@ inline int persist_launch(PersistBuffers &b, const uint8_t *pool, const Frame &f
   }
   {
     const int fill = spare_kernel ? b.max_per_cu_spare : (desc ? b.max_per_cu_desc : b.max_per_cu);
-    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (b.in_ring ? std::min(kRingWavesPerCu, fill) : (b.in_overlap ? std::min(kOverlapWavesPerCu, fill) : fill));
+    int per_cu = b.waves_per_cu > 0 ? b.waves_per_cu : (b.in_ring ? std::min(kRingWavesPerCu, fill) : (b.in_overlap ? std::min(overlap_waves_per_cu(b.overlap_sets), fill) : fill));
     b.blocks = (b.cus - b.cus_reserved) * per_cu;
     b.last_per_cu = per_cu;
   }

@@ -565,9 +565,9 @@ class HipContext:
         self._chk(self._L.svo_pick_info(self._h, ctypes.byref(x), ctypes.byref(y), ctypes.byref(m), ctypes.byref(w)))
         return {"x": x.value, "y": y.value, "from_mail": int(m.value), "waited": int(w.value)}
 
-    def set_overlap(self, on):
-        """dispatch_async alternates two {stream, image} sets (default on)"""
-        self._chk(self._L.svo_set_overlap(self._h, 1 if on else 0))
+    def set_overlap(self, sets):
+        """image sets dispatch_async takes turns on: False / 0 = one (no alternation), True / 1 = the library's default, 2 .. 8 = that many"""
+        self._chk(self._L.svo_set_overlap(self._h, int(sets)))
 
     def sync(self):
         self._chk(self._L.svo_sync(self._h))

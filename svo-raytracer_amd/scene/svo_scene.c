@@ -61,6 +61,7 @@ typedef struct {
 typedef struct {
   int C, G;         /* cell edge in voxels, cells per axis (N / C) */
   uint8_t *val;     /* per cell: 0xff = no ball, 0 = the ball carves (air), 1..3 = the ball is solid, of that material */
+  uint8_t *pres;    /* a bit per cell: a ball is present (2 MB for the finest level of an 8192^3 world: stays in the caches) */
   uint16_t *cx, *cy, *cz, *r;
   int nocc;         /* occupancy pyramid: occ[j][cell of edge C << j] = a ball is present somewhere inside */
   uint8_t **occ;
@@ -185,7 +186,7 @@ static inline uint8_t state_upto(const scene_t *s, int upto, int x, int y, int z
   for (int k = upto - 1; k >= 0; k--) {
     const ball_level_t *b = &s->ball[k];
     size_t ci = ((size_t)(z / b->C) * b->G + (size_t)(y / b->C)) * b->G + (size_t)(x / b->C);
-    if (b->val[ci] != 0xff && in_ball(b, ci, x, y, z)) return b->val[ci];
+    if ((b->pres[ci >> 3] >> (ci & 7) & 1) && in_ball(b, ci, x, y, z)) return b->val[ci];
   }
   return terrain_voxel(s, x, y, z);
 }
@@ -194,10 +195,45 @@ static inline uint8_t voxel(const scene_t *s, int x, int y, int z) {
   return s->nball ? state_upto(s, s->nball, x, y, z) : terrain_voxel(s, x, y, z);
 }
 
+/* Does any ball share a voxel with the box [x0, x1] x [y0, y1] x [z0, z1] (inclusive, any alignment)?  Exact for boxes that span
+   few cells of a level; a box over many cells of a level answers from that level's presence bits alone (1 = "maybe": the
+   callers then take the general path, which is exact either way).  Where the answer is 0 the scene IS the terrain inside the
+   box, and the height-field shortcuts of family 0 apply: nearly every voxel of an 8192^3 world. */
+static int balls_touch(const scene_t *s, int x0, int y0, int z0, int x1, int y1, int z1) {
+  const int N = s->N;
+  if (x0 < 0) x0 = 0;
+  if (y0 < 0) y0 = 0;
+  if (z0 < 0) z0 = 0;
+  if (x1 > N - 1) x1 = N - 1;
+  if (y1 > N - 1) y1 = N - 1;
+  if (z1 > N - 1) z1 = N - 1;
+  if (x0 > x1 || y0 > y1 || z0 > z1) return 0;
+  for (int k = 0; k < s->nball; k++) {
+    const ball_level_t *b = &s->ball[k];
+    const int cx0 = x0 / b->C, cx1 = x1 / b->C, cy0 = y0 / b->C, cy1 = y1 / b->C, cz0 = z0 / b->C, cz1 = z1 / b->C;
+    const long ncell = (long)(cx1 - cx0 + 1) * (cy1 - cy0 + 1) * (cz1 - cz0 + 1);
+    for (int iz = cz0; iz <= cz1; iz++)
+      for (int iy = cy0; iy <= cy1; iy++)
+        for (int ix = cx0; ix <= cx1; ix++) {
+          const size_t ci = ((size_t)iz * b->G + (size_t)iy) * b->G + (size_t)ix;
+          if (!(b->pres[ci >> 3] >> (ci & 7) & 1)) continue;
+          if (ncell > 27) return 1;
+          int c0[3] = {x0, y0, z0}, c1[3] = {x1, y1, z1}, bc[3] = {b->cx[ci], b->cy[ci], b->cz[ci]};
+          int64_t r2 = (int64_t)b->r[ci] * b->r[ci], dn = 0;
+          for (int a = 0; a < 3; a++) {
+            const int64_t near = bc[a] < c0[a] ? c0[a] - bc[a] : bc[a] > c1[a] ? bc[a] - c1[a] : 0;
+            dn += near * near;
+          }
+          if (dn <= r2) return 1;
+        }
+  }
+  return 0;
+}
+
 static void free_balls(scene_t *s) {
   for (int k = 0; k < s->nball; k++) {
     ball_level_t *b = &s->ball[k];
-    free(b->val); free(b->cx); free(b->cy); free(b->cz); free(b->r);
+    free(b->val); free(b->pres); free(b->cx); free(b->cy); free(b->cz); free(b->r);
     if (b->occ) for (int j = 0; j < b->nocc; j++) free(b->occ[j]);
     free(b->occ);
   }
@@ -242,6 +278,9 @@ static int make_balls(scene_t *s, int dens) {
           if (!near) continue;
           b->val[ci] = sc ? 0 : (uint8_t)(1 + ((hp >> 8) % 3));
         }
+    b->pres = (uint8_t *)calloc((n + 7) / 8, 1);
+    for (size_t i = 0; i < n; i++)
+      if (b->val[i] != 0xff) b->pres[i >> 3] |= (uint8_t)(1u << (i & 7));
     /* occupancy pyramid */
     int nocc = 1;
     while ((G >> (nocc - 1)) > 1) nocc++;
@@ -431,7 +470,8 @@ static void first_nonzero3(const scene_t *s, int cx, int cy, int cz, int cs, uin
 
 /* classify region [cx,cx+cs) x [cy,cy+cs) x [cz,cz+cs); value per Octree.java:528-555 */
 static int classify(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *value) {
-  if (cs >= 8 && s->nball) {
+  const int touched = s->nball && balls_touch(s, cx, cy, cz, cx + cs - 1, cy + cs - 1, cz + cs - 1);
+  if (cs >= 8 && touched) {
     uint8_t hv;
     int k = homog3(s, cx, cy, cz, cs, &hv);
     if (k != K_MIXED) { *value = hv; return k; }
@@ -453,24 +493,25 @@ static int classify(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *v
     if (cy + cs - 1 <= mn - 5) { *value = 1; return K_SOLID; }
     /* mixed (an all-solid region of edge >= 6 touching the 5-layer
        material band always also contains material 1) */
-    uint8_t v0 = voxel(s, cx, cy, cz);
+    uint8_t v0 = terrain_voxel(s, cx, cy, cz);   /* (no ball touches this cube: the scene is the terrain here) */
     if (v0) { *value = v0; return K_MIXED; }
     /* first non-zero sample in the reference's z, y, x scan order: solid voxels of a
        column form a prefix in y, so the first one is found on the y = cy plane */
     for (int z = cz; z < cz + cs; z++) {
       const uint16_t *row = s->h + (size_t)z * s->N;
       for (int x = cx; x < cx + cs; x++)
-        if (row[x] >= cy) { *value = voxel(s, x, cy, z); return K_MIXED; }
+        if (row[x] >= cy) { *value = terrain_voxel(s, x, cy, z); return K_MIXED; }
     }
     *value = 0; /* unreachable: mx >= cy */
     return K_EMPTY;
   }
-  uint8_t first = voxel(s, cx, cy, cz), val = first;
+#define VOX(x, y, z) (touched ? voxel(s, x, y, z) : terrain_voxel(s, x, y, z))
+  uint8_t first = VOX(cx, cy, cz), val = first;
   if (cs == 1) { *value = first; return first ? K_SOLID : K_EMPTY; }
   for (int z = cz; z < cz + cs; z++)
     for (int y = cy; y < cy + cs; y++)
       for (int x = cx; x < cx + cs; x++) {
-        uint8_t smp = voxel(s, x, y, z);
+        uint8_t smp = VOX(x, y, z);
         if (smp) val = smp;
         if (smp != first) {
           if (first == 0) first = smp;
@@ -480,11 +521,13 @@ static int classify(const scene_t *s, int cx, int cy, int cz, int cs, uint8_t *v
       }
   *value = val;
   return val ? K_SOLID : K_EMPTY;
+#undef VOX
 }
 
 /* Octree.java:620-649 */
 static int surface_normal(const scene_t *s, int cx, int cy, int cz, uint16_t *packed) {
   int exposed = 0, nx = 0, ny = 0, nz = 0;
+  const int touched = s->nball && balls_touch(s, cx - 1, cy - 1, cz - 1, cx + 1, cy + 1, cz + 1);
   for (int i = cx - 1; i <= cx + 1; i++) {
     if (i < 0 || i >= s->N || !in_chunk(s, i, cx)) continue;
     for (int k = cz - 1; k <= cz + 1; k++) {
@@ -492,7 +535,7 @@ static int surface_normal(const scene_t *s, int cx, int cy, int cz, uint16_t *pa
       int h = H(s, i, k);
       for (int j = cy - 1; j <= cy + 1; j++) {
         if (j < 0 || j >= s->N || !in_chunk(s, j, cy)) continue;
-        if (s->nball ? voxel(s, i, j, k) == 0 : j > h) { exposed = 1; nx += i - cx; ny += j - cy; nz += k - cz; }
+        if (touched ? voxel(s, i, j, k) == 0 : j > h) { exposed = 1; nx += i - cx; ny += j - cy; nz += k - cz; }
       }
     }
   }
@@ -503,6 +546,7 @@ static int surface_normal(const scene_t *s, int cx, int cy, int cz, uint16_t *pa
 
 /* Octree.java:651-670: only coordinates {c-1, c+cs, c+cs+1} on every axis are looked at */
 static int big_node_exposed(const scene_t *s, int cx, int cy, int cz, int cs) {
+  const int touched = s->nball && balls_touch(s, cx - 1, cy - 1, cz - 1, cx + cs + 1, cy + cs + 1, cz + cs + 1);
   int ax[3][3] = {{cx - 1, cx + cs, cx + cs + 1}, {cy - 1, cy + cs, cy + cs + 1}, {cz - 1, cz + cs, cz + cs + 1}};
   int c0[3] = {cx, cy, cz};
   for (int a = 0; a < 3; a++)
@@ -512,7 +556,7 @@ static int big_node_exposed(const scene_t *s, int cx, int cy, int cz, int cs) {
         if (x < 0 || x >= s->N || !in_chunk(s, x, c0[0])) continue;
         if (y < 0 || y >= s->N || !in_chunk(s, y, c0[1])) continue;
         if (z < 0 || z >= s->N || !in_chunk(s, z, c0[2])) continue;
-        if (voxel(s, x, y, z) == 0) return 1;
+        if ((touched ? voxel(s, x, y, z) : terrain_voxel(s, x, y, z)) == 0) return 1;
       }
   return 0;
 }
@@ -524,6 +568,14 @@ static void build_children(const scene_t *s, buf_t *b, counts_t *cnt, size_t par
                            int size) {
   int cs = size / 2;
   if (cs == 0) return;
+  /* family 1: a subtree no ball comes near (two voxels of margin: the normals look one voxel out, the exposure test two) IS the
+     terrain's -- walk it as family 0, without asking again further down */
+  scene_t plain;
+  if (s->nball && !balls_touch(s, px - 2, py - 2, pz - 2, px + size + 1, py + size + 1, pz + size + 1)) {
+    plain = *s;
+    plain.nball = 0;
+    s = &plain;
+  }
   size_t child_off[8];
   uint8_t child_val[8];
   int child_type[8];

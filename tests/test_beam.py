@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+import poolcache
+
 from helpers import compare_with_golden, golden_case, golden_cases
 import helpers
 
@@ -99,7 +101,7 @@ def test_config3_with_beam_equals_config3_without(ctx, pipeline):
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd.cameras import CAMERAS
     from oracle import oracle
-    pool, _ = scene.build_scene(8192)
+    pool = poolcache.pool()
     ctx.set_pipeline(pipeline)
     for cam in ("K1", "K2"):
         plain = ctx.render(pool if cam == "K1" else None, 1920, 1080, CAMERAS[cam], 2, 0)

@@ -8,6 +8,8 @@ import zlib
 import numpy as np
 import pytest
 
+import poolcache
+
 import svo_raytracer_amd.scene as scene
 import helpers
 
@@ -21,7 +23,7 @@ def _cases():
 @pytest.fixture(scope="module")
 def pool8192():
     z = np.load(GOLD)
-    pool, _ = scene.build_scene(8192)
+    pool = poolcache.pool()
     assert pool.size == int(z["pool_size"][0]) and zlib.crc32(pool.tobytes()) == int(z["pool_crc32"][0]), \
         "scene generator drifted: regenerate tests/golden/config3_8192.npz"
     return pool

@@ -6,6 +6,8 @@ import os
 
 import numpy as np
 import pytest
+
+import poolcache
 import helpers
 
 pytestmark = pytest.mark.gpu
@@ -233,7 +235,7 @@ def test_config5_8192_1080p_64_samples_per_pixel():
     from svo_raytracer_amd import hiplib
     from svo_raytracer_amd.cameras import CAMERAS
     from oracle import oracle
-    pool, _ = scene.build_scene(8192)
+    pool = poolcache.pool()
     c = helpers.DualContext()
     try:
         w, h, step = 1920, 1080, 32

@@ -9,6 +9,8 @@ import ctypes
 import numpy as np
 import pytest
 
+import poolcache
+
 from helpers import compare_with_golden, golden_case, golden_cases
 
 pytestmark = pytest.mark.gpu
@@ -258,7 +260,7 @@ def pool8192():
     import svo_raytracer_amd.scene as scene
     from test_config3 import GOLD
     z = np.load(GOLD)
-    pool, _ = scene.build_scene(8192)
+    pool = poolcache.pool()
     assert pool.size == int(z["pool_size"][0]) and zlib.crc32(pool.tobytes()) == int(z["pool_crc32"][0])
     return pool
 

@@ -19,9 +19,8 @@ def ctx():
 
 @pytest.fixture(scope="module")
 def pool8192():
-    import svo_raytracer_amd.scene as scene
-    pool, st = scene.build_scene(8192)
-    return pool
+    import poolcache
+    return poolcache.pool()
 
 
 class Frames:

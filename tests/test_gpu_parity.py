@@ -210,9 +210,9 @@ def _check_subsampled(ctx, pool, w, h, cam, frame, mode, step, **opts):
 
 @pytest.fixture(scope="module")
 def pool8192():
-    import svo_raytracer_amd.scene as scene
-    pool, st = scene.build_scene(8192)
-    assert st["depth"] == 13 and pool.size < 2**31
+    import poolcache
+    pool = poolcache.pool()
+    assert pool.size < 2**31
     return pool
 
 

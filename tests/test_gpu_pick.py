@@ -146,7 +146,7 @@ def test_overlapped_dispatches_leave_the_bytes_of_one_stream(ctx):
             for k in ("rgba", "hits"):
                 assert (got[k] == single[i][k]).all(), (f, k)
             assert (got["depth"].view(np.uint32) == single[i]["depth"].view(np.uint32)).all(), f
-    assert len(ptrs) == 2 and p0[0] in ptrs          # two image sets took turns
+    assert len(ptrs) == 4 and p0[0] in ptrs          # four image sets took turns (the default)
     ctx.sync()
     got = _frame(ctx)
     assert (got["rgba"] == single[-1]["rgba"]).all() and (got["hits"] == single[-1]["hits"]).all()
@@ -250,7 +250,7 @@ def test_what_an_enqueued_dispatch_leaves_for_a_host_that_does_not_read_back(ctx
         want[f] = ctx.read_color()
     t_wait = ctx.stats()["last_dispatch_ms"]
     seen = []
-    for f in (3, 4, 5):
+    for f in (3, 4, 5, 3, 4):
         ctx.set_params(f, 0, 0, 0, 2, 0, 1)
         ctx.dispatch_async()
         assert ctx.stats()["last_dispatch_ms"] == t_wait          # not this frame's time: nothing waited for it
@@ -259,7 +259,17 @@ def test_what_an_enqueued_dispatch_leaves_for_a_host_that_does_not_read_back(ctx
         ctx.sync()                                                # ... after which the device image is the frame
         dev = ctx.dev_read(col_ptr, w * h * 4).reshape(h, w, 4)
         assert (dev == want[f]).all(), f
-    assert seen[0] != seen[1] and seen[0] == seen[2]              # two image sets in turn
+    assert len(set(seen)) == 4 and seen[0] == seen[4]             # four image sets in turn (the default) ...
+    ctx.set_overlap(2)                                            # ... or as many as asked for
+    two = []
+    for f in (3, 4, 5, 3):
+        ctx.set_params(f, 0, 0, 0, 2, 0, 1)
+        ctx.dispatch_async()
+        two.append(ctx.output_device_ptrs()[0])
+    ctx.sync()
+    assert len(set(two)) == 2 and two[0] == two[2] and two[1] == two[3]
+    with pytest.raises(Exception):
+        ctx.set_overlap(9)
     ctx.set_overlap(False)
     ptrs = set()
     for f in (3, 4):

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+import poolcache
+
 pytestmark = pytest.mark.gpu
 
 
@@ -67,7 +69,7 @@ def test_spare_kernel_renders_the_reference_shader_s_config3_and_config4_frames(
     from test_config3 import GOLD, _check, _meta
     z = np.load(GOLD)
     step = int(z["step"][0])
-    pool, _ = scene.build_scene(8192)
+    pool = poolcache.pool()
     monkeypatch.setenv("SVO_SPARE", "1")
     ctx = hiplib.HipContext(0, lib_path=hiplib.VARIANTS_LIB_PATH)
     try:

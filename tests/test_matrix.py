@@ -11,6 +11,8 @@ import zlib
 import numpy as np
 import pytest
 
+import poolcache
+
 import helpers
 import svo_raytracer_amd.scene as scene
 
@@ -41,11 +43,10 @@ def big(request):
     z = Z()
     sk = request.param
     family, seed, amp, dens = (str(v) for v in z[sk + "/scene"])
-    pool, _ = scene.build(family, 8192, int(seed), int(amp), int(dens))
+    pool = poolcache.pool(family, 8192, int(seed), int(amp), int(dens))
     assert pool.size == int(z[sk + "/pool_size"][0]) and zlib.crc32(pool.tobytes()) == int(z[sk + "/pool_crc32"][0]), \
         "scene generator drifted: regenerate tests/golden/matrix_golden.npz"
     yield sk, pool
-    del pool
 
 
 def _small_case(name, pk):

@@ -42,6 +42,9 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 SVO_BENCH_BACKEND=gloo SVO_BENCH_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --exchange copy --waves 5 $B --isolated 0 2>/dev/null | line > $O/bench_two_ranks_one_gpu_copy.json
 for n in 2 8; do SVO_BENCH_ONE_GPU=1 python bench.py --gpus $n --driver group --exchange copy $B --steps 100 --warmup 12 2>/dev/null | line > $O/bench_group${n}_one_gpu.json; done
 python tests/config_table.py > $O/config_table.md 2>&1; cat $O/config_table.md
+# round 6: the measurement matrix (cameras K0 / K1 / K2 x three scenes) and the reference's loop by launch shape
+python tools/matrix.py --out $O/matrix > $O/matrix.log 2>&1; tail -12 $O/matrix.log | cut -c1-200
+python tools/loop_shape.py 0 24 16 12 10 > $O/loop_shape.log 2>&1; cp gpurun_out/loop_shape.txt $O/loop_shape.txt
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 120 --warmup 12 --cpu-seconds 0 --verify 0 --isolated 0 --moving 0 --default-abi 0 --long-steps 0 > $GRAFT_REPO_ROOT/$O/trace.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_k20 -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --verify 0 --moving 0 --default-abi 0 --long-steps 0 > $GRAFT_REPO_ROOT/$O/trace_k20.log 2>&1
