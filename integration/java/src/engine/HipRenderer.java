@@ -357,11 +357,16 @@ public class HipRenderer {
   }
 
   /**
-   * svo_set_overlap: dispatchCompute alternates two {stream, image} sets so that frame N + 1 starts in frame N's tail (default
-   * on); read-backs always see the last dispatched frame.  false = one stream, one image set.
+   * svo_set_overlap: dispatchCompute takes turns on several {stream, image} sets so that a frame starts in the tails of the frames
+   * before it (default: four sets, up to four frames in flight); read-backs always see the last dispatched frame.  false = one
+   * stream, one image set; setOverlap(int sets) names the number (2 .. 8).
    */
   public void setOverlap(boolean enabled) {
     check(nSetOverlap(ctx, enabled ? 1 : 0));
+  }
+
+  public void setOverlap(int sets) {
+    check(nSetOverlap(ctx, sets));
   }
 
   /** svo_set_stream: a caller-owned hipStream_t (0 = the library's own). */

@@ -68,7 +68,7 @@ struct svo_ctx {
   uint32_t *own_color = nullptr;
   float *own_depth = nullptr;
   uint4 *own_hits = nullptr;
-  // svo_dispatch_async alternates two sets {stream, images} while the library owns both (the reference's loop, Main.java:132-146,
+  // svo_dispatch_async takes turns on `overlap` sets {stream, images} while the library owns them (the reference's loop, Main.java:132-146,
   // 257-289: frame N + 1 starts in frame N's tail): set 0 = own_stream + own_*, sets 1 .. overlap - 1 = alt_* (made on first use).
   // c->stream / c->d_* always name ONE set, the one of the last dispatch, so every read-back sees the last dispatched frame.
   static constexpr int kMaxSets = 8;

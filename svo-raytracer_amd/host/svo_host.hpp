@@ -313,7 +313,7 @@ class Renderer {
   // renders the pixel has stored it -- the frame need not have ended (round 6); anywhere else it waits for the frame.
   float readDepthPixel(int x, int y) { float d = 0.0f; if (ensure()) check(svo_read_pixel(ctx, x, y, nullptr, &d, nullptr)); return d; }
   void setPick(int x, int y) { if (ensure()) check(svo_set_pick(ctx, x, y)); }          // x < 0: no pick, every read-back waits
-  void setOverlap(bool on) { if (ensure()) check(svo_set_overlap(ctx, on ? 1 : 0)); }   // two {stream, image} sets in turn (default on)
+  void setOverlap(int sets) { if (ensure()) check(svo_set_overlap(ctx, sets)); }   // {stream, image} sets dispatchCompute takes turns on: 0 = one, 1 = default (4), 2 .. 8
   // dormant shader features (svotrace.comp:444, 500-504, 668-670); defaults = the live behaviour
   void setPathOptions(int bounces_, uint32_t mirrorMask_, int spp_) { bounces = bounces_; mirrorMask = mirrorMask_; spp = spp_; }
   svo_ctx *context() { ensure(); return ctx; }

@@ -119,7 +119,7 @@ def test_pick_positions_and_the_frames_that_carry_none(ctx):
 
 
 def test_overlapped_dispatches_leave_the_bytes_of_one_stream(ctx):
-    """frames 2..13 dispatched back to back (two sets alternating, up to two frames in flight) against the same frames on one
+    """frames 2..13 dispatched back to back (four image sets in turn, up to four frames in flight) against the same frames on one
     stream and one image set; a read-back always names the LAST dispatched frame"""
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd.cameras import CAMERAS
@@ -231,7 +231,7 @@ def test_what_an_enqueued_dispatch_leaves_for_a_host_that_does_not_read_back(ctx
     """dispatchCompute of both host mirrors enqueues (svo_dispatch_async).  A host that looks at svo_get_stats or at the
     device images right behind it, without a read-back, sees the frame only after svo_sync: last_dispatch_ms is the GPU time of
     the last WAITING dispatch (svo_dispatch), never of an enqueued one, and svo_output_device_ptrs names the images of the last
-    dispatched frame -- which alternate between two sets while the library owns them."""
+    dispatched frame -- which take turns on four sets while the library owns them."""
     import svo_raytracer_amd.scene as scene
     from svo_raytracer_amd.cameras import CAMERAS
     pool, _ = scene.build_scene(256)
