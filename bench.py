@@ -598,14 +598,18 @@ def run_reference_loop(pool, W, H, cam, args, nframes=300, warm=30):
                     fnums(last), step, npx, bad)
             return r
 
-        static = leg([cam], lambda i: 2 + i, "static camera, frameNumber 2, 3, ... (Main.java:275)")
+        static = leg([cam], lambda i: 2 + i, "static camera, frameNumber 2, 3, ... (Main.java:275); the library's defaults: four image sets in turn, "
+                                              "the pick answered by a one-wave launch of its own")
         mcams, _ = orbit_path(warm + nframes + 4, start=args.camera)
         moving = leg(list(mcams), lambda i: 1, "a camera that moves every frame (Camera.rotate + strafe through the host mirror), frameNumber 1 on every frame")
+        ok(nSetOverlap(j, 2), "nSetOverlap")
+        two_sets = leg([cam], lambda i: 2 + i, "static camera; TWO image sets in turn (svo_set_overlap 2: at most two frames in flight), pick from the mail")
         ok(nSetOverlap(j, 0), "nSetOverlap")
         pick_only = leg([cam], lambda i: 2 + i, "static camera; one stream and one image set (svo_set_overlap 0), pick from the mail")
         ok(nSetPick(j, -1, -1), "nSetPick")
         neither = leg([cam], lambda i: 2 + i, "static camera; one stream, one image set, no pick: every read-back waits for its frame (round 5's loop)")
-        return {"static": static, "moving": moving, "without_overlap": pick_only, "without_overlap_and_pick": neither,
+        return {"static": static, "moving": moving, "two_image_sets": two_sets, "without_overlap": pick_only, "without_overlap_and_pick": neither,
+                "image_sets": "library default (svo_set_overlap 1 = four sets in turn: up to four frames in flight, each launch 8 persistent waves per CU)",
                 "calls_per_frame": "nSetCamera, nSetParams, nDispatchAsync, nReadPixel(%d, %d) -- JNI-typed exports, wall clock, a context of its own" % (cx, cy)}
     finally:
         nDestroy(j)

@@ -63,4 +63,47 @@ int svoh_render_frame(void *octree, void *camera, int width, int height, int fra
   return 0;
 }
 
+// Main.updateEarly for n frames, as the reference's loop runs it (Main.java:130-289): per frame the crosshair depth of the frame
+// before (readDepthPixel at the image centre -- Main reads it at the top of updateEarly, :132-146), the camera's motion
+// (rotate + strafe when `move`; any motion resets frameNumber to 0, :225-233), frameNumber++ (:275), the uniforms, the dispatch.
+// picks[i] = the crosshair depth of frame i (read at the top of frame i + 1's turn, the last one after the loop); cams = the
+// 15 uniform floats of every frame (n x 15) and frame_numbers what each frame was rendered with, for the checker.
+// Returns 0, or 1 if the renderer reported an error.
+int svoh_render_loop(void *octree, void *camera, int width, int height, int nframes, int render_mode, int move, float *picks,
+                     float *cams, int *frame_numbers, uint8_t *last_rgba, float *last_depth) {
+  Renderer &renderer = Renderer::getInstance();
+  Octree *oct = (Octree *)octree;
+  Camera *cam = (Camera *)camera;
+  Renderer::Shader *traceShader = renderer.getShaderByName("svotrace");
+  if (!traceShader) traceShader = renderer.addShader("svotrace", "src/shaders/svotrace.comp");
+  renderer.setImageSize(width, height);
+  renderer.addSSBO(7, oct->getByteBuffer(), (size_t)oct->memOffset);
+  int frameNumber = 1;                                        // Main.java:16
+  const int gx = (width + 7) / 8, gy = (height + 7) / 8;
+  for (int i = 0; i < nframes; i++) {
+    if (i > 0) picks[i - 1] = renderer.readDepthPixel(width / 2, height / 2);   // :132-146, the frame dispatched last turn
+    if (move) { cam->rotate(0.0f, 0.01f, 0.0f); cam->strafe(0.002f, 0.001f); frameNumber = 0; }   // :161-236
+    renderer.useProgram(traceShader);
+    renderer.setUniform3fv(8, cam->pos);
+    renderer.setUniform3fv(1, cam->l1);
+    renderer.setUniform3fv(2, cam->l2);
+    renderer.setUniform3fv(3, cam->r1);
+    renderer.setUniform3fv(4, cam->r2);
+    frameNumber++;
+    renderer.setUniformInteger(5, frameNumber);
+    renderer.setUniformInteger(6, render_mode);
+    renderer.setUniformInteger(9, oct->memOffset);
+    renderer.setUniformInteger(11, 0);
+    renderer.dispatchCompute(traceShader, gx, gy, 1);
+    if (cams) cam->getUniform(cams + 15 * (size_t)i);
+    if (frame_numbers) frame_numbers[i] = frameNumber;
+    if (renderer.hasError()) { renderer.printGLErrors(); return 1; }
+  }
+  if (nframes > 0) picks[nframes - 1] = renderer.readDepthPixel(width / 2, height / 2);
+  if (last_rgba) renderer.readFramebuffer(last_rgba);
+  if (last_depth) renderer.readDepth(last_depth);
+  if (renderer.hasError()) { renderer.printGLErrors(); return 1; }
+  return 0;
+}
+
 }  // extern "C"

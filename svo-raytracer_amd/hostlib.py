@@ -160,3 +160,22 @@ def render_frame(octree, camera, width, height, frame_number=2, render_mode=2):
     if rc != 0:
         raise RuntimeError("Renderer reported an error (see stdout)")
     return rgba, depth
+
+
+def render_loop(octree, camera, width, height, nframes, render_mode=0, move=True):
+    """Main.updateEarly for `nframes` frames through the C++ Renderer mirror (needs a GPU): returns (picks float32 [n] -- the
+    crosshair depth of every frame, read the way Main reads it, one turn later --, cams float32 [n][15], frame numbers int32 [n],
+    the last frame's rgba8 and depth images)."""
+    picks = np.zeros(nframes, dtype=np.float32)
+    cams = np.zeros((nframes, 15), dtype=np.float32)
+    fns = np.zeros(nframes, dtype=np.int32)
+    rgba = np.zeros((height, width, 4), dtype=np.uint8)
+    depth = np.zeros((height, width), dtype=np.float32)
+    L = lib()
+    L.svoh_render_loop.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 5
+    L.svoh_render_loop.restype = ctypes.c_int
+    rc = L.svoh_render_loop(octree._h, camera._h, width, height, nframes, render_mode, 1 if move else 0, picks.ctypes.data,
+                            cams.ctypes.data, fns.ctypes.data, rgba.ctypes.data, depth.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("Renderer reported an error (see stdout)")
+    return picks, cams, fns, rgba, depth

@@ -105,3 +105,27 @@ def test_renderer_mirror_drives_one_frame_like_main():
         ref = oracle.render(pool, 200, 120, c.getUniform(), 2, mode)
         assert (rgba == ref["rgba"]).all()
         assert (depth.view(np.uint32) == ref["depth"].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("move", [True, False])
+def test_renderer_mirror_runs_main_s_loop_with_the_crosshair_pick(move):
+    """Main.updateEarly for 24 frames written against the C++ mirror (host/svo_host.cpp::svoh_render_loop): the crosshair depth of
+    every frame -- read one turn later, as Main reads it, from the mail of the frame's pick launch while up to four frames are
+    in flight -- and the last frame's images == the oracle with that frame's camera and frameNumber."""
+    from oracle import oracle
+    pool, _ = scene.build_scene(256)
+    o = hostlib.Octree(4096)
+    o.adopt(pool)
+    c = hostlib.Camera()
+    c.setPos(1.5, 1.42, 1.5)
+    c.setSpeed(1.0)
+    c.rotate(-0.5, 0.3, 0.0)
+    w, h, n = 320, 184, 24
+    picks, cams, fns, rgba, depth = hostlib.render_loop(o, c, w, h, n, 0, move)
+    assert (fns == 1).all() if move else (fns == np.arange(2, 2 + n)).all()      # Main.java:225-233, 275
+    for i in range(n):
+        ref = oracle.render(pool, w, h, cams[i], int(fns[i]), 0, rows=(h // 2, h // 2 + 1), want_hits=False)
+        assert ref["depth"].view(np.uint32)[h // 2, w // 2] == picks.view(np.uint32)[i], i
+    ref = oracle.render(pool, w, h, cams[-1], int(fns[-1]), 0, want_hits=False)
+    assert (rgba == ref["rgba"]).all() and (depth.view(np.uint32) == ref["depth"].view(np.uint32)).all()
