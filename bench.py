@@ -625,7 +625,7 @@ def stamps_for(key):
     e = j.get(key)      # (no fall-back to another launch shape's entry: a line carries its own shape's figures or none)
     if not e or e.get("src_hash") != source_hash():
         return None
-    return {k: v for k, v in e.items() if k != "src_hash"}
+    return {k: v for k, v in e.items() if k not in ("src_hash", "all")}      # ("all": the other launch shapes of the same pass)
 
 
 def probe_command(args, exchange):
