@@ -76,6 +76,8 @@ struct svo_ctx {
   uint32_t *alt_color[kMaxSets] = {};
   float *alt_depth[kMaxSets] = {};
   uint4 *alt_hits[kMaxSets] = {};
+  hipEvent_t set_done[kMaxSets] = {};        // behind the last overlapped dispatch into each set (incl. set 0): a set is rendered
+  bool set_used[kMaxSets] = {};              // into again only once that frame is complete -- at most `overlap` frames are queued
   int cur_set = 0;
   int overlap = 4;             // image sets svo_dispatch_async takes turns on (svo_set_overlap; 1 = no alternation)
   bool alt_inflight = false;   // a set that is not current may still have a frame in flight
@@ -220,6 +222,7 @@ static void free_outputs(svo_ctx *c) {
   }
   if (c->cur_set != 0 && (c->is_own_stream(c->stream) || c->stream == nullptr)) c->stream = c->own_stream;
   c->cur_set = 0; c->alt_inflight = false; c->pick_live = false;
+  for (int k = 0; k < svo_ctx::kMaxSets; k++) c->set_used[k] = false;
   if (!c->external_outputs) { c->d_color = nullptr; c->d_depth = nullptr; c->d_hits = nullptr; }
 #if SVO_VARIANTS
   wavefront_free(c->wf);
@@ -250,6 +253,7 @@ int svo_destroy(svo_ctx *c) {
   for (void *p : c->ipc_opened) if (p) (void)hipIpcCloseMemHandle(p);
   for (void *p : c->dev_allocs) if (p) (void)hipFree(p);
   for (int k = 1; k < svo_ctx::kMaxSets; k++) if (c->alt_stream[k]) (void)hipStreamDestroy(c->alt_stream[k]);
+  for (int k = 0; k < svo_ctx::kMaxSets; k++) if (c->set_done[k]) (void)hipEventDestroy(c->set_done[k]);
   if (c->pick_stream) (void)hipStreamDestroy(c->pick_stream);
   if (c->pick_mail) (void)hipHostFree(c->pick_mail);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -939,6 +943,10 @@ int svo_dispatch_async(svo_ctx *c) {
         HIPCHK(c, hipMemsetAsync(c->alt_hits[k], 0, n * 16, c->alt_stream[k]));
       }
     }
+    // the host runs ahead of the GPU by at most `overlap` frames (a swap chain's depth): the set's previous frame must be complete
+    // (the pick launches do not throttle it any more: they need a wave slot, not the frame's turn)
+    if (!c->set_done[k]) HIPCHK(c, hipEventCreateWithFlags(&c->set_done[k], hipEventDisableTiming));
+    if (c->set_used[k]) HIPCHK(c, hipEventSynchronize(c->set_done[k]));
     c->cur_set = k;
     c->stream = c->set_stream(k);
     c->d_color = k ? c->alt_color[k] : c->own_color; c->d_depth = k ? c->alt_depth[k] : c->own_depth; c->d_hits = k ? c->alt_hits[k] : c->own_hits;
@@ -951,7 +959,12 @@ int svo_dispatch_async(svo_ctx *c) {
     rc = launch_frame(c, false);
     if (rc) c->pick_live = false;
   }
+  const bool overlapped = c->pb.in_overlap;
   c->pb.in_overlap = false;
+  if (overlapped && rc == SVO_OK) {
+    HIPCHK(c, hipEventRecord(c->set_done[c->cur_set], c->stream));
+    c->set_used[c->cur_set] = true;
+  }
   return rc;
 }
 
