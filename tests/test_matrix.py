@@ -165,3 +165,65 @@ def test_hip_matches_the_reference_shader_on_the_matrix_cells(big):
             ctx.ring_destroy()
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------ the beam pre-pass on the new family
+# (floating debris and overhangs are what a conservative coarse depth pass must survive: a 4x4 block's pyramid may graze a ball
+# that none of its sixteen rays' neighbours on the terrain sees)
+
+def _beam_bad(res, g):
+    bad = helpers.compare_with_golden(res, g)
+    bad.pop("iter")                       # fewer iterations is the point
+    if g["mode"] == 1:
+        bad.pop("rgba")                   # renderMode 1 displays the iteration count
+    return bad
+
+
+@pytest.mark.parametrize("name,pk", _small())
+def test_oracle_with_beam_matches_the_reference_shader_on_the_caves_family(name, pk):
+    from oracle import oracle
+    g = _small_case(name, pk)
+    res = oracle.render(g["pool"], g["w"], g["h"], g["cam"], g["frame"], g["mode"], use_beam=True)
+    bad = _beam_bad(res, g)
+    assert bad == {k: 0 for k in bad}, (name, bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_hip_with_beam_matches_the_reference_shader_on_the_caves_family(pipeline):
+    from oracle import oracle
+    ctx = helpers.DualContext()
+    try:
+        ctx.set_pipeline(pipeline)
+        last = None
+        for name, pk in _small():
+            g = _small_case(name, pk)
+            res = ctx.render(g["pool"] if pk != last else None, g["w"], g["h"], g["cam"], g["frame"], g["mode"], use_beam=1)
+            last = pk
+            bad = _beam_bad(res, g)
+            assert bad == {k: 0 for k in bad}, (name, bad)
+            ref = oracle.render(g["pool"], g["w"], g["h"], g["cam"], g["frame"], g["mode"], use_beam=True)
+            assert np.array_equal(ctx.read_beam().view(np.uint32), ref["beam"].view(np.uint32)), name     # the coarse pass, bit for bit
+            assert (res["hits"]["iter"] == ref["hits"]["iter"]).all(), name
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_with_beam_on_the_full_size_caves_scene():
+    """8192^3 caves, 1080p, K1 and K2, mode 0: every byte of the frame without the beam pass except the iteration counts"""
+    from svo_raytracer_amd.cameras import CAMERAS
+    ctx = helpers.DualContext()
+    try:
+        ctx.set_pipeline(1)
+        ctx.pool_upload(poolcache.pool("caves", 8192, 1, 8, 64))
+        for cam in ("K1", "K2"):
+            plain = ctx.render(None, 1920, 1080, CAMERAS[cam], 2, 0)
+            beam = ctx.render(None, 1920, 1080, CAMERAS[cam], 2, 0, use_beam=1)
+            assert (beam["rgba"] == plain["rgba"]).all() and (beam["depth"].view(np.uint32) == plain["depth"].view(np.uint32)).all()
+            for k in ("pointer", "value", "raw_normal", "level"):
+                assert (beam["hits"][k] == plain["hits"][k]).all(), (cam, k)
+            assert (beam["hits"]["t"].view(np.uint32) == plain["hits"]["t"].view(np.uint32)).all()
+            assert int(beam["hits"]["iter"].sum()) < int(plain["hits"]["iter"].sum())
+    finally:
+        ctx.close()
