@@ -239,7 +239,8 @@ int svo_dispatch_async(svo_ctx *ctx);
  *     the CUs frame N's tail frees.  svo_read_color / _depth / _hits / _pixel and svo_output_device_ptrs always name the LAST
  *     dispatched frame (GL's semantics: a read-back sees the last dispatch) and wait for it alone; svo_sync waits for all.
  *     svo_set_overlap(ctx, n): 0 = no alternation (one stream, one image set, as before round 6), 1 = the default (4 sets: up
- *     to four frames in flight, like a swap chain), 2 .. 8 = that many sets.
+ *     to four frames in flight, like a swap chain), 2 .. 8 = that many sets.  The host never runs further ahead than that:
+ *     before a set is rendered into again svo_dispatch_async waits for the set's previous frame to be complete.
  *   - the pick pixel -- svo_set_pick(x, y); default the image centre, Main.java:139-141 -- is answered without waiting for its
  *     frame: in front of the frame's kernels a launch of ONE wave on a high-priority stream of its own walks that pixel's path
  *     (the same device functions on the same values: the same bits) and writes {rgba8, depth, hit record} and the dispatch's

@@ -278,3 +278,88 @@ def test_what_an_enqueued_dispatch_leaves_for_a_host_that_does_not_read_back(ctx
         ptrs.add(ctx.output_device_ptrs()[0])
     ctx.sync()
     assert len(ptrs) == 1                                         # one set, as before round 6
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_mixes_of_overlapped_dispatches_picks_and_state_changes(seed):
+    """The alternation's bookkeeping under a random host: number of image sets, pick position, pipeline, image size, camera,
+    render mode and frame number change between dispatches; some frames are read back whole, of some only the pick, some not at
+    all; svo_sync and waiting dispatches come in between.  Every value read must be what a second context renders synchronously
+    (one stream, one image set, no pick) for the same state."""
+    import svo_raytracer_amd.scene as scene
+    from svo_raytracer_amd import hiplib
+    from svo_raytracer_amd.cameras import CAMERAS
+    rng = np.random.RandomState(seed)
+    pool, _ = scene.build_scene3(256, 1, 8, 96)
+    ctx, ref = hiplib.HipContext(0), hiplib.HipContext(0)
+    try:
+        sizes = [(208, 120), (131, 77)]
+        w, h = sizes[0]
+        for c in (ctx, ref):
+            c.pool_upload(pool)
+            c.resize(w, h)
+        ref.set_overlap(0)
+        ref.set_pick(-1, -1)
+        cams = [CAMERAS["K0"], CAMERAS["K1"], CAMERAS["K2"]]
+        cache = {}
+
+        def want(key):
+            if key not in cache:
+                (ww, hh), ci, frame, mode, pipe = key
+                ref.resize(ww, hh)
+                ref.set_pipeline(pipe)
+                cache[key] = ref.render(None, None, None, cams[ci], frame, mode)
+            return cache[key]
+
+        pick = (w // 2, h // 2)
+        frame, last = 2, None
+        for step in range(60):
+            r = rng.rand()
+            if r < 0.12:
+                ctx.set_overlap(int(rng.choice([0, 1, 2, 3, 5, 8])))
+            elif r < 0.24:
+                if rng.rand() < 0.25:
+                    ctx.set_pick(-1, -1)
+                    pick = None
+                else:
+                    pick = (int(rng.randint(0, w)), int(rng.randint(0, h)))
+                    ctx.set_pick(*pick)
+            elif r < 0.30:
+                w, h = sizes[int(rng.randint(0, 2))]
+                ctx.resize(w, h)
+                if pick is not None and (pick[0] >= w or pick[1] >= h):
+                    pick = None                               # (svo_resize drops a pick that fell outside the new image)
+                    assert ctx.pick_info()["x"] == -1
+            elif r < 0.36:
+                ctx.sync()
+            pipe = int(rng.choice([1, 1, 1, 0]))
+            ctx.set_pipeline(pipe)
+            ci, mode = int(rng.randint(0, 3)), int(rng.choice([0, 0, 2, 3]))
+            ctx.set_camera(cams[ci])
+            ctx.set_params(frame, mode, 0, 0, 2, 0, 1)
+            key = ((w, h), ci, frame, mode, pipe)
+            if rng.rand() < 0.15:
+                ctx.dispatch()
+            else:
+                ctx.dispatch_async()
+            frame += int(rng.randint(0, 3))
+            tag = (seed, step, key)
+            what = rng.rand()
+            if what < 0.45 and pick is not None:
+                i0 = ctx.pick_info()
+                px = ctx.read_pixel(*pick)
+                i1 = ctx.pick_info()
+                assert i1["from_mail"] == i0["from_mail"] + 1, tag       # whole frames, one sample: every such frame has its pick launch
+                _pixel_matches(px, want(key), pick[0], pick[1])
+            elif what < 0.75:
+                got, exp = _frame(ctx), want(key)
+                assert (got["rgba"] == exp["rgba"]).all(), tag
+                assert (got["depth"].view(np.uint32) == exp["depth"].view(np.uint32)).all(), tag
+                assert (got["hits"] == exp["hits"]).all(), tag
+            elif what < 0.85:
+                x, y = int(rng.randint(0, w)), int(rng.randint(0, h))
+                _pixel_matches(ctx.read_pixel(x, y), want(key), x, y)
+        ctx.sync()
+    finally:
+        ctx.close()
+        ref.close()
