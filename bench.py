@@ -302,7 +302,8 @@ def launch_ranks(args, argv=None, runner=run_rung):
 
 
 KERNEL_SOURCES = ("svo_persistent.hip.h", "svo_travloop2.h", "svo_trav2.h", "svo_derive.hip.h", "svo_descword.h", "svo_travloop.h", "svo_trav.h",
-                  "svo_device.h", "svo_fused.hip.h", "svo_kernels.h", "svo_travloop3.h", "svo_persist2.hip.h", "Makefile")
+                  "svo_device.h", "svo_fused.hip.h", "svo_kernels.h", "Makefile")
+# (the comparators' sources -- csrc/variants/ -- are not in it: a run on them carries SVO_HIP_LIB / SVO_SPARE in its key, below)
 # environment switches that select another kernel or another data path than the default's: PMC / stamps figures are keyed by them
 KERNEL_ENV = ("SVO_SPARE", "SVO_RC_TABLE", "SVO_NORMAL_TABLE", "SVO_DERIVED", "SVO_FORCE_CAMS", "SVO_HIP_LIB")
 

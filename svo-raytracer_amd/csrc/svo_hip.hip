@@ -23,10 +23,10 @@
 #include "svo_fused.hip.h"
 #include "svo_persistent.hip.h"
 #if SVO_ASM_LOOP && SVO_VARIANTS
-#include "svo_persist2.hip.h"
+#include "variants/svo_persist2.hip.h"
 #endif
 #if SVO_VARIANTS
-#include "svo_wavefront.hip.h"
+#include "variants/svo_wavefront.hip.h"
 #endif
 #include "svo_build.hip.h"
 #include "svo_beam.hip.h"

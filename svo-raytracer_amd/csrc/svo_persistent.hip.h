@@ -66,7 +66,7 @@ struct PersistArgs {
   uint32_t desc_count;
   // per-frame cameras and frame numbers of a batch (svo_ring_submit_cams), f.batch entries; only read by the kCams kernels
   const FrameVar *fvar;
-  // path records of the spare-ray kernel (svo_persist2.hip.h): kRecWaveWords words per persistent wave of the launch
+  // path records of the spare-ray kernel (variants/svo_persist2.hip.h): kRecWaveWords words per persistent wave of the launch
   uint32_t *prec;
   int spare;   // 1 = launch the spare-ray kernel
   // row / column tables of the launch's frames (rc_table_kernel; only read by the kTab kernels): per frame rc_stride floats =
@@ -644,7 +644,7 @@ struct PersistBuffers {
   int blocks = 0;
   int thresh_num = 0;   // sixteenths; 0 = the running kernel's default: 9 for persist_kernel (8 / 9 / 10 / 11: 4.28 / 4.38 / 4.33 /
                         // 4.14 Grays/s, tools/history/sweep8.sh), SVO_SPARE_THRESH for the spare-ray kernel
-  int spare_mode = 0;   // 1 = the spare-ray kernel (svo_persist2.hip.h) on walkable pools (environment SVO_SPARE=1: round 5's
+  int spare_mode = 0;   // 1 = the spare-ray kernel (variants/svo_persist2.hip.h) on walkable pools (environment SVO_SPARE=1: round 5's
                         // experiment, measured slower than persist_kernel with launches in flight); 0 = persist_kernel everywhere
   const float4 *ntab = nullptr;   // the context's normal table (made with the context; survives persist_free)
   int ntab_mode = 1;              // environment SVO_NORMAL_TABLE=0: decode in place
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(SVO_RC_BLOCK) void rc_table_kernel(const Frame f, F
   }
 }
 
-// the spare-ray kernel (svo_persist2.hip.h, included behind this file by svo_hip.hip in SVO_VARIANTS builds)
+// the spare-ray kernel (variants/svo_persist2.hip.h, included behind this file by svo_hip.hip in SVO_VARIANTS builds)
 #ifndef SVO_VARIANTS
 #define SVO_VARIANTS 0
 #endif

@@ -21,7 +21,7 @@
 // a parked slot instead of the traversal registers): same bytes, checked by the whole parity suite on this kernel (it is
 // what pipeline 1 ran while it was the default) and against persist_kernel itself (tests/test_gpu_spare.py).
 #pragma once
-#include "svo_persistent.hip.h"
+#include "../svo_persistent.hip.h"
 #include "svo_travloop3.h"
 
 namespace svo {

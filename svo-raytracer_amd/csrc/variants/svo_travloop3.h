@@ -18,7 +18,7 @@
 // lane's two path records belongs to the ray being traversed (the slot's ray owns the other); conem / scone = the
 // traversing / the slot's ray is a cone (secondary) ray.
 #pragma once
-#include "svo_travloop2.h"
+#include "../svo_travloop2.h"
 
 namespace svo {
 

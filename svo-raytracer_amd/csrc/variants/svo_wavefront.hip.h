@@ -17,10 +17,10 @@
 // (each frame uses its own buffer set from a small ring): another frame's kernels fill the gap.
 // Results are bit-identical to pipelines 0 / 1 and to the oracle: same cast and shading arithmetic per ray.
 #pragma once
-#include "svo_device.h"
-#include "svo_fused.hip.h"
-#include "svo_kernels.h"
-#include "svo_trav.h"
+#include "../svo_device.h"
+#include "../svo_fused.hip.h"
+#include "../svo_kernels.h"
+#include "../svo_trav.h"
 
 #include <cstdlib>
 

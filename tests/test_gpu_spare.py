@@ -1,4 +1,4 @@
-"""The spare-ray kernel (svo-raytracer_amd/csrc/svo_persist2.hip.h + svo_travloop3.h; round 5's experiment on the lanes that
+"""The spare-ray kernel (svo-raytracer_amd/csrc/variants/svo_persist2.hip.h + svo_travloop3.h; round 5's experiment on the lanes that
 wait for a round, opt-in through SVO_SPARE=1 because it lost the throughput A/B: profiles/round5_experiments.txt) must leave the
 bytes persist_kernel leaves -- every render mode, path options, samples and progressive sequences in one launch, frames with
 their own cameras, the beam pre-pass -- and the reference shader's own image of the benchmark's configuration."""
