@@ -94,7 +94,8 @@ def parse(argv=None):
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel accumulated per frame (svotrace.comp:668-670)")
     ap.add_argument("--seq", type=int, default=None, help="frames of the cross-frame accumulation (svotrace.comp:712-719) per step: "
                                                           "one step = frameNumber 2 .. seq + 1 blended into one image (svo_set_sequence)")
-    ap.add_argument("--camera", default="K1", help="K0 (the reference's default, Main.java:120), K1, K2 (grazing): SURVEY 8(d)")
+    ap.add_argument("--camera", default="K1", help="K0 (the reference's default, Main.java:120), K1, K2 (grazing): SURVEY 8(d); CAVE (with --scene caves): "
+                                                   "inside the scene's largest cave")
     ap.add_argument("--scene", choices=["terrain", "caves"], default="terrain",
                     help="scene family: terrain = the integer-noise height field (SURVEY 8d), built on the GPU from its two maps; caves = "
                          "the same terrain under levels of hashed balls that carve it or float over it (overhangs, cave mouths, boulders, "
@@ -733,7 +734,13 @@ def main(argv=None, ctx_factory=None):
     from svo_raytracer_amd.framering import FrameRing, GroupAsContext, GroupRing, replicate_pool
 
     W, H = args.width, args.height
-    cam = CAMERAS[args.camera]
+    if args.camera == "CAVE":       # a camera inside the largest cave of the "caves" scene (cameras.cave_camera): not one of SURVEY 8(d)'s
+        if args.scene != "caves":
+            raise SystemExit("bench.py: --camera CAVE needs --scene caves")
+        from svo_raytracer_amd.cameras import cave_camera
+        cam = cave_camera(args.size, args.seed, args.amp, args.dens)
+    else:
+        cam = CAMERAS[args.camera]
     # ngpu: GPUs that share a frame -- the ranks of the torch driver, or the members of ONE process's group (svo_group_*)
     ngpu = args.gpus if group_mode else world
     group = None

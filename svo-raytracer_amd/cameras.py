@@ -38,3 +38,12 @@ def orbit_path(n, start="K1", yaw_step=0.004, pitch_step=0.0, forward=0.0004, si
         cam.strafe(forward, side)
         out[i] = cam.getUniform()
     return out, np.ones(n, dtype=np.int32)
+
+
+def cave_camera(n=8192, seed=1, amp=8, dens=None):
+    """A camera INSIDE the largest cave of the "caves" scene (scene.cave_position), looking along the terrain (pitch -0.1, yaw
+    0.7): the one view of the matrix from which the scene is concave everywhere -- walls all around, the sky through the cave's
+    mouth.  Not one of SURVEY 8(d)'s cameras; `--camera CAVE` of bench.py and tools/matrix.py, with --scene caves."""
+    from . import scene
+    pos, _ = scene.cave_position(n, seed, amp, scene.CAVES_DENS if dens is None else dens)
+    return rot_cam(pos, -0.1, 0.7)

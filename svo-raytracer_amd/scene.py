@@ -112,6 +112,32 @@ def scene3_ball_counts(n, seed=1, amp=8, dens=CAVES_DENS):
     return [[int(a), int(b)] for a, b in c]
 
 
+def scene3_balls(n, seed=1, amp=8, dens=CAVES_DENS, max_balls=1 << 16):
+    """int32 [count][6] = {level, cx, cy, cz, r, value (0 = carving)} of a family-1 scene's balls, coarse levels first"""
+    L = lib()
+    L.svo_scene3_balls.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.svo_scene3_balls.restype = ctypes.c_int
+    out = np.zeros((max_balls, 6), dtype=np.int32)
+    cnt = L.svo_scene3_balls(int(n), int(seed), int(amp), int(dens), out.ctypes.data, int(max_balls))
+    return out[:min(cnt, max_balls)].copy()
+
+
+def cave_position(n, seed=1, amp=8, dens=CAVES_DENS):
+    """World position (in [1, 2]^3) of the centre of the largest cave of a family-1 scene: the carving ball of the largest radius
+    among those of the coarsest level that has any -- where bench.py --camera CAVE and tests/golden/make_golden_matrix.py put a
+    camera that sees the scene from the inside."""
+    b = scene3_balls(n, seed, amp, dens)
+    carve = b[b[:, 5] == 0]
+    if carve.shape[0] == 0:
+        raise RuntimeError("the scene has no carving ball")
+    inner = carve[((carve[:, 1:4] - 2 * carve[:, 4:5] >= 0) & (carve[:, 1:4] + 2 * carve[:, 4:5] < n)).all(axis=1)]   # not at a world face
+    if inner.shape[0]:
+        carve = inner
+    lvl = carve[carve[:, 0] == carve[:, 0].min()]
+    c = lvl[np.argmax(lvl[:, 4])]
+    return tuple(1.0 + (float(v) + 0.5) / float(n) for v in c[1:4]), int(c[4])
+
+
 def build(family, n, seed=1, amp=8, dens=CAVES_DENS):
     """pool, stats of scene family "terrain" or "caves" """
     if family == "terrain":

@@ -700,6 +700,28 @@ int svo_scene3_ball_counts(int N, uint32_t seed, int amp_num, int dens, uint64_t
   return rc;
 }
 
+/* the balls of a family-1 scene: out[i] = {level, cx, cy, cz, r, value (0 = carving)}, at most `max` of them, coarse levels
+   first; returns how many there are (tests, and the camera bench.py places inside a cave: --camera CAVE) */
+int svo_scene3_balls(int N, uint32_t seed, int amp_num, int dens, int32_t *out, int max) {
+  scene_t s;
+  int n = 0;
+  if (scene_setup(&s, N, seed, amp_num, dens) == 0)
+    for (int k = 0; k < s.nball; k++) {
+      const ball_level_t *b = &s.ball[k];
+      const size_t cells = (size_t)b->G * b->G * b->G;
+      for (size_t i = 0; i < cells; i++) {
+        if (b->val[i] == 0xff) continue;
+        if (n < max && out) {
+          int32_t *o = out + 6 * (size_t)n;
+          o[0] = k; o[1] = b->cx[i]; o[2] = b->cy[i]; o[3] = b->cz[i]; o[4] = b->r[i]; o[5] = b->val[i];
+        }
+        n++;
+      }
+    }
+  free_scene(&s);
+  return n;
+}
+
 static int scene_build(int N, uint32_t seed, int amp_num, int dens, uint8_t **out_pool, uint64_t *out_len, svo_scene_stats *st) {
   if (N < 8 || N > 8192 || (N & (N - 1))) return 1;
   scene_t s;

@@ -18,7 +18,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import svo_raytracer_amd.scene as scene  # noqa: E402
-from svo_raytracer_amd.cameras import CAMERAS  # noqa: E402
+from svo_raytracer_amd.cameras import CAMERAS, cave_camera  # noqa: E402
+
+CAMERAS = dict(CAMERAS, CAVE=cave_camera(8192, 1, 8, 64))     # inside the largest cave of the caves scene
 
 SHADER = "/root/reference/src/shaders/svotrace.comp"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
@@ -29,7 +31,7 @@ SCENES = {"t1a8": ("terrain", 1, 8, 0), "t2a18": ("terrain", 2, 18, 0), "c1a8d64
 FULL = [("t1a8_K2_f2", "t1a8", "K2", 2, 0),
         ("t2a18_K0_f2", "t2a18", "K0", 2, 0), ("t2a18_K1_f2", "t2a18", "K1", 2, 0), ("t2a18_K2_f5", "t2a18", "K2", 5, 0),
         ("c1a8d64_K0_f2", "c1a8d64", "K0", 2, 0), ("c1a8d64_K1_f2", "c1a8d64", "K1", 2, 0), ("c1a8d64_K2_f2", "c1a8d64", "K2", 2, 0),
-        ("c1a8d64_K1_m2", "c1a8d64", "K1", 2, 2)]
+        ("c1a8d64_K1_m2", "c1a8d64", "K1", 2, 2), ("c1a8d64_CAVE_f2", "c1a8d64", "CAVE", 2, 0)]
 # small, pools stored: pool key -> (n, seed, amp, dens)
 SMALL_POOLS = {"c128": (128, 1, 8, 64), "c256": (256, 2, 8, 128)}
 

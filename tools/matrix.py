@@ -65,7 +65,7 @@ def main():
                     v = [r[3] for r in rows if r[0] == w and r[1] == t and r[3]]
                     f.write("| %d | %d | %s | %.0f |\n" % (w, t, " / ".join("%.0f" % x for x in v), sum(v) / max(len(v), 1)))
         return
-    cells = [sk + "_" + c for sk in SCENES for c in CAMS] if a.cells == "all" else a.cells.split(",")
+    cells = ([sk + "_" + c for sk in SCENES for c in CAMS] + ["c1a8d64_CAVE"]) if a.cells == "all" else a.cells.split(",")
     lines = {}
     for cell in cells:
         j = run_bench(cell, [], env)

@@ -16,6 +16,9 @@ elif _cache and os.path.exists(_cache):
     ctx.pool_upload(np.load(_cache))
 else:
     ctx.pool_upload(scene.build(SCENE, 8192, SEED, AMP)[0])
+if CAMERA == "CAVE":
+    from svo_raytracer_amd.cameras import cave_camera
+    CAMERAS = dict(CAMERAS, CAVE=cave_camera(8192, SEED, AMP))
 ctx.resize(1920, 1080); ctx.set_camera(CAMERAS[CAMERA]); ctx.set_hit_records(False); ctx.set_pipeline(1)
 L = hiplib.lib()
 L.svo_debug_heads.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
