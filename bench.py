@@ -507,7 +507,7 @@ def run_reference_loop(pool, W, H, cam, args, nframes=300, warm=30):
     import ctypes
     import numpy as np
     from svo_raytracer_amd import hiplib
-    from svo_raytracer_amd.cameras import orbit_path
+    from svo_raytracer_amd.cameras import CAMERAS, orbit_path
     L = hiplib.lib()
     vp, jint, jlong, jfloat = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
@@ -602,7 +602,7 @@ def run_reference_loop(pool, W, H, cam, args, nframes=300, warm=30):
 
         static = leg([cam], lambda i: 2 + i, "static camera, frameNumber 2, 3, ... (Main.java:275); the library's defaults: four image sets in turn, "
                                               "the pick answered by a one-wave launch of its own")
-        mcams, _ = orbit_path(warm + nframes + 4, start=args.camera)
+        mcams, _ = orbit_path(warm + nframes + 4, start=(args.camera if args.camera in CAMERAS else cam))
         moving = leg(list(mcams), lambda i: 1, "a camera that moves every frame (Camera.rotate + strafe through the host mirror), frameNumber 1 on every frame")
         ok(nSetOverlap(j, 2), "nSetOverlap")
         two_sets = leg([cam], lambda i: 2 + i, "static camera; TWO image sets in turn (svo_set_overlap 2: at most two frames in flight), pick from the mail")
@@ -824,7 +824,7 @@ def main(argv=None, ctx_factory=None):
     path = None
     if args.camera_path == "orbit":
         from svo_raytracer_amd.cameras import orbit_path
-        path = orbit_path(args.warmup + args.steps + 8, start=args.camera)
+        path = orbit_path(args.warmup + args.steps + 8, start=(args.camera if args.camera in CAMERAS else cam))
 
     # ---- ray count (untimed counting pass of the first and the last timed frame) ---------------------
     def count(frame):    # on the context's own stream and images (the ring's slots are not involved)
@@ -968,7 +968,7 @@ def main(argv=None, ctx_factory=None):
         try:
             from svo_raytracer_amd.cameras import orbit_path
             msteps = max(args.steps, 4 * batch * nbuf)
-            mpath = orbit_path(msteps + 4 * batch * nbuf, start=args.camera)
+            mpath = orbit_path(msteps + 4 * batch * nbuf, start=(args.camera if args.camera in CAMERAS else cam))
             midx = sorted({2 * batch * nbuf + (msteps - 1) * i // 8 for i in range(9)})
             mrays = []
             for i in midx:

@@ -28,7 +28,7 @@ def orbit_path(n, start="K1", yaw_step=0.004, pitch_step=0.0, forward=0.0004, si
     (Main.java:225-233, 275)."""
     from . import hostlib
     cam = hostlib.Camera()
-    p = CAMERAS[start][:3]
+    p = CAMERAS[start][:3] if isinstance(start, str) else np.asarray(start, dtype=np.float32)[:3]     # a camera's name, or a position
     cam.setPos(float(p[0]), float(p[1]), float(p[2]))
     cam.setSpeed(1.0)
     cam.rotate(-0.5, 0.3, 0.0)     # K1's attitude, through the reference's own rotate()
