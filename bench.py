@@ -96,13 +96,15 @@ def parse(argv=None):
                                                           "one step = frameNumber 2 .. seq + 1 blended into one image (svo_set_sequence)")
     ap.add_argument("--camera", default="K1", help="K0 (the reference's default, Main.java:120), K1, K2 (grazing): SURVEY 8(d); CAVE (with --scene caves): "
                                                    "inside the scene's largest cave")
-    ap.add_argument("--scene", choices=["terrain", "caves"], default="terrain",
+    ap.add_argument("--scene", choices=["terrain", "caves", "dust"], default="terrain",
                     help="scene family: terrain = the integer-noise height field (SURVEY 8d), built on the GPU from its two maps; caves = "
                          "the same terrain under levels of hashed balls that carve it or float over it (overhangs, cave mouths, boulders, "
-                         "floating debris: scene/svo_scene.c family 1), built on the host cores and uploaded")
+                         "floating debris: scene/svo_scene.c family 1), built on the host cores and uploaded; dust = the terrain under a "
+                         "field of floating particles (family 2: the hostile case of an octree walk, 200 - 400 iterations per ray)")
     ap.add_argument("--seed", type=int, default=1, help="seed of the scene's integer noise")
     ap.add_argument("--amp", type=int, default=8, help="terrain amplitude in sixteenths of an octave's cell (8 = the default terrain)")
-    ap.add_argument("--dens", type=int, default=None, help="caves: probability / 256 that a cell next to a surface holds a ball (default 64)")
+    ap.add_argument("--dens", type=int, default=None, help="caves: probability / 256 that a cell next to a surface holds a ball (default 64); "
+                                                           "dust: probability / 256 that an air cell of the dust level holds a particle (default 24)")
     ap.add_argument("--ref-loop", type=int, default=None, help="(default: as --default-abi) also time the reference's own loop -- per frame nSetCamera, nSetParams, nDispatchAsync, "
                                                             "nReadPixel at the crosshair, through JNI-typed calls, wall clock (value_one_frame_at_a_time; "
                                                             "one GPU, default pipeline)")
@@ -754,16 +756,16 @@ def main(argv=None, ctx_factory=None):
     # svo_build_from_heightmap), replicated by one RCCL broadcast ------------------------------------------
     t_build = time.time()
     pool = None
-    if rank == 0 and args.scene == "caves":
-        # family 1 has no height map to build from: the host cores make the pool, svo_pool_upload copies it (Renderer.addSSBO)
-        dens = scene.CAVES_DENS if args.dens is None else args.dens
+    if rank == 0 and args.scene in ("caves", "dust"):
+        # families 1 and 2 have no height map to build from: the host cores make the pool, svo_pool_upload copies it (Renderer.addSSBO)
+        dens = (scene.CAVES_DENS if args.scene == "caves" else scene.DUST_DENS) if args.dens is None else args.dens
         # (tools/matrix.py runs several cells on one scene: SVO_SCENE_CACHE = a directory that keeps the pool between runs)
         cached = os.environ.get("SVO_SCENE_CACHE") and os.path.join(os.environ["SVO_SCENE_CACHE"],
-                                                                    "caves_%d_s%d_a%d_d%d.npy" % (args.size, args.seed, args.amp, dens))
+                                                                    "%s_%d_s%d_a%d_d%d.npy" % (args.scene, args.size, args.seed, args.amp, dens))
         if cached and os.path.exists(cached):
             pool = np.load(cached)
         else:
-            pool, _ = scene.build_scene3(args.size, args.seed, args.amp, dens)
+            pool, _ = scene.build_scene3(args.size, args.seed, args.amp, dens if args.scene == "caves" else 0, dens if args.scene == "dust" else 0)
             if cached:
                 np.save(cached, pool)
         nbytes = int(pool.size)
@@ -1163,8 +1165,10 @@ def main(argv=None, ctx_factory=None):
                 "workload": "%s: %d^3 procedural %s SVO (seed %d, amplitude %d/16, %d bytes), %dx%d, renderMode %d (%s), %s, camera %s, "
                             "%s, pipeline %d, %s" % (
                                 args.config or "C3", args.size,
-                                "terrain" if args.scene == "terrain" else "caves (terrain + %d/256 hashed balls: overhangs, cave mouths, debris)" % (
-                                    scene.CAVES_DENS if args.dens is None else args.dens),
+                                "terrain" if args.scene == "terrain" else
+                                ("caves (terrain + %d/256 hashed balls: overhangs, cave mouths, debris)" % (scene.CAVES_DENS if args.dens is None else args.dens)
+                                 if args.scene == "caves" else
+                                 "dust (terrain + floating particles in %d/256 of the air cells of edge N/256)" % (scene.DUST_DENS if args.dens is None else args.dens)),
                                 args.seed, args.amp, nbytes, W, H_total, args.mode,
                                 ("primary + %d bounce(s)%s" % (args.bounces - 1, ", mirror mask 0x%x" % args.mirror if args.mirror else ""))
                                 if args.mode == 0 else ("primary + shadow ray" if args.mode == 2 else "primary only"),

@@ -76,15 +76,22 @@ def build_scene(n, seed=1, amp=8):
 # "family 1": craters and cave mouths under overhanging rims, boulders, arches, floating debris -- real 3-D structure,
 # the integer analogue of the Worley part of the reference's chunkgen.comp:228-233).
 CAVES_DENS = 64     # dens / 256 = probability that a cell next to a surface holds a ball: 2.04 GB at 8192^3 (limit 2^31)
+# "dust" (family 2): the terrain under a field of floating particles (balls of radius 1 or 2 in cells of edge N / 256) -- the
+# hostile case of an octree walk: rays do not hit the particles, they descend into every coarse cell that holds one.
+DUST_DENS = 24      # dust / 256 = probability that an air cell of the dust level holds a particle
 
 
-def build_scene3(n, seed=1, amp=8, dens=CAVES_DENS):
-    """Build an n^3 family-1 ("caves") SVO.  Returns (pool: np.uint8[len], stats dict)."""
+def _d(dens, dust):
+    return int(dens) | (int(dust) << 16)      # (the C entry points take the dust level's density in bits 16.. of `dens`)
+
+
+def build_scene3(n, seed=1, amp=8, dens=CAVES_DENS, dust=0):
+    """Build an n^3 family-1 ("caves": dens > 0) / family-2 ("dust": dust > 0) SVO.  Returns (pool: np.uint8[len], stats dict)."""
     L = lib()
     p = ctypes.POINTER(ctypes.c_uint8)()
     ln = ctypes.c_uint64()
     st = SceneStats()
-    rc = L.svo_scene_build3(int(n), int(seed), int(amp), int(dens), ctypes.byref(p), ctypes.byref(ln), ctypes.byref(st))
+    rc = L.svo_scene_build3(int(n), int(seed), int(amp), _d(dens, dust), ctypes.byref(p), ctypes.byref(ln), ctypes.byref(st))
     if rc != 0:
         raise RuntimeError(f"svo_scene_build3({n}) failed rc={rc} (3 = pool would exceed 2^31 bytes: {ln.value})")
     try:
@@ -94,19 +101,19 @@ def build_scene3(n, seed=1, amp=8, dens=CAVES_DENS):
     return pool, st.as_dict()
 
 
-def scene3_voxels(n, seed=1, amp=8, dens=CAVES_DENS):
+def scene3_voxels(n, seed=1, amp=8, dens=CAVES_DENS, dust=0):
     """The dense voxels grid[z, y, x] of a family-1 scene (n <= 1024): what the brute-force builders start from."""
     g = np.zeros((n, n, n), dtype=np.uint8)
-    rc = lib().svo_scene3_voxels(int(n), int(seed), int(amp), int(dens), g.ctypes.data)
+    rc = lib().svo_scene3_voxels(int(n), int(seed), int(amp), _d(dens, dust), g.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"svo_scene3_voxels({n}) failed rc={rc}")
     return g
 
 
-def scene3_ball_counts(n, seed=1, amp=8, dens=CAVES_DENS):
-    """[[carving, solid] per level] of a family-1 scene"""
-    c = np.zeros((4, 2), dtype=np.uint64)
-    rc = lib().svo_scene3_ball_counts(int(n), int(seed), int(amp), int(dens), c.ctypes.data)
+def scene3_ball_counts(n, seed=1, amp=8, dens=CAVES_DENS, dust=0):
+    """[[carving, solid] per level] of a family-1 / family-2 scene (the dust level, if any, comes last)"""
+    c = np.zeros((5, 2), dtype=np.uint64)
+    rc = lib().svo_scene3_ball_counts(int(n), int(seed), int(amp), _d(dens, dust), c.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"svo_scene3_ball_counts({n}) failed rc={rc}")
     return [[int(a), int(b)] for a, b in c]
@@ -138,13 +145,15 @@ def cave_position(n, seed=1, amp=8, dens=CAVES_DENS):
     return tuple(1.0 + (float(v) + 0.5) / float(n) for v in c[1:4]), int(c[4])
 
 
-def build(family, n, seed=1, amp=8, dens=CAVES_DENS):
-    """pool, stats of scene family "terrain" or "caves" """
+def build(family, n, seed=1, amp=8, dens=CAVES_DENS, dust=DUST_DENS):
+    """pool, stats of scene family "terrain", "caves" or "dust" """
     if family == "terrain":
         return build_scene(n, seed, amp)
     if family == "caves":
         return build_scene3(n, seed, amp, dens)
-    raise ValueError("scene family %r (terrain | caves)" % (family,))
+    if family == "dust":
+        return build_scene3(n, seed, amp, 0, dust)
+    raise ValueError("scene family %r (terrain | caves | dust)" % (family,))
 
 
 def scene_maps(n, seed=1, amp=8):

@@ -57,7 +57,7 @@ typedef struct {
 
 /* family 1 ("caves"): levels of hashed balls over the terrain (below).  A level = a grid of cells of edge C; a cell
    holds at most one ball, wholly inside the cell. */
-#define MAX_BALL_LEVELS 4
+#define MAX_BALL_LEVELS 5   /* four levels of balls next to surfaces + the dust level (family 2) */
 typedef struct {
   int C, G;         /* cell edge in voxels, cells per axis (N / C) */
   uint8_t *val;     /* per cell: 0xff = no ball, 0 = the ball carves (air), 1..3 = the ball is solid, of that material */
@@ -241,11 +241,20 @@ static void free_balls(scene_t *s) {
 }
 
 /* fill the level tables, coarse to fine (a level's balls look at the state the coarser levels left) */
+/* `dens`: low 16 bits = probability / 256 of a ball in a cell next to a surface (family 1, above); bits 16.. = `dust`, the
+   probability / 256 that a cell of the DUST level holds a particle (family 2): cells of edge max(8, N / 256), a particle =
+   a ball of radius 1 or 2 floating in the air -- its centre and the six points r + 1 along the axes are empty -- of a hashed
+   material.  Dust is the hostile case of an octree walk: a ray does not hit the particles, it descends into every coarse cell
+   that holds one and steps through its fine cells (iterations per ray go up several-fold, sky rays are no longer cheap). */
 static int make_balls(scene_t *s, int dens) {
   int N = s->N;
-  for (int k = 0; k < MAX_BALL_LEVELS; k++) {
-    int C = N >> (2 + 2 * k);
-    if (C < 8) break;
+  const int dust = dens >> 16;
+  dens &= 0xffff;
+  int levels = 0;
+  while (dens > 0 && levels < MAX_BALL_LEVELS - 1 && (N >> (2 + 2 * levels)) >= 8) levels++;
+  for (int k = 0; k < levels + (dust > 0 ? 1 : 0); k++) {
+    const int is_dust = k == levels;
+    int C = is_dust ? (N / 256 > 8 ? N / 256 : 8) : N >> (2 + 2 * k);
     ball_level_t *b = &s->ball[k];
     memset(b, 0, sizeof *b);
     b->C = C; b->G = N / C;
@@ -262,15 +271,24 @@ static int make_balls(scene_t *s, int dens) {
           size_t ci = ((size_t)iz * G + iy) * G + ix;
           uint32_t hr = cell_hash(s->seed, k, ix, iy, iz, 1), hc = cell_hash(s->seed, k, ix, iy, iz, 2);
           uint32_t hp = cell_hash(s->seed, k, ix, iy, iz, 3);
-          int r = C / 8 + (int)(hr % (uint32_t)(C / 4 + 1));
+          int r = is_dust ? 1 + (int)(hr & 1u) : C / 8 + (int)(hr % (uint32_t)(C / 4 + 1));
           int span = C - 2 * r; /* centre in [cell + r, cell + C - 1 - r] */
           int cx = ix * C + r + (int)((hc & 0x3ff) * (uint32_t)span >> 10);
           int cy = iy * C + r + (int)(((hc >> 10) & 0x3ff) * (uint32_t)span >> 10);
           int cz = iz * C + r + (int)(((hc >> 20) & 0x3ff) * (uint32_t)span >> 10);
           b->cx[ci] = (uint16_t)cx; b->cy[ci] = (uint16_t)cy; b->cz[ci] = (uint16_t)cz; b->r[ci] = (uint16_t)r;
           b->val[ci] = 0xff;
-          if ((int)(hp & 0xff) >= dens) continue;
+          if ((int)(hp & 0xff) >= (is_dust ? dust : dens)) continue;
           uint8_t sc = state_upto(s, k, cx, cy, cz);
+          if (is_dust) { /* a particle floats: nothing solid at its centre nor just outside it along the axes */
+            int clear = sc == 0;
+            for (int a = 0; a < 6 && clear; a++) {
+              static const int dx[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+              clear = state_upto(s, k, cx + (r + 1) * dx[a][0], cy + (r + 1) * dx[a][1], cz + (r + 1) * dx[a][2]) == 0;
+            }
+            if (clear) b->val[ci] = (uint8_t)(1 + ((hp >> 8) % 3));
+            continue;
+          }
           int D = sc ? r : 2 * r, near = 0;
           static const int ax[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
           for (int a = 0; a < 6 && !near; a++)
@@ -667,13 +685,13 @@ int svo_scene_build(int N, uint32_t seed, int amp_num, uint8_t **out_pool, uint6
 /* family 1: the terrain with levels of hashed balls over it (caves, overhangs, boulders, floating debris; see "family 1"
    above).  dens / 256 = the probability that a cell next to a surface holds a ball, 0 .. 256. */
 int svo_scene_build3(int N, uint32_t seed, int amp_num, int dens, uint8_t **out_pool, uint64_t *out_len, svo_scene_stats *st) {
-  if (dens < 0 || dens > 256) return 1;
+  if (dens < 0 || (dens & 0xffff) > 256 || (dens >> 16) > 256) return 1;   /* (bits 16..: the dust level of family 2, make_balls) */
   return scene_build(N, seed, amp_num, dens, out_pool, out_len, st);
 }
 
 /* the dense voxels of a family-1 scene, grid[z][y][x] (tests: the brute-force builders start from these) */
 int svo_scene3_voxels(int N, uint32_t seed, int amp_num, int dens, uint8_t *grid) {
-  if (N < 8 || N > 1024 || (N & (N - 1)) || dens < 0 || dens > 256 || !grid) return 1;
+  if (N < 8 || N > 1024 || (N & (N - 1)) || dens < 0 || (dens & 0xffff) > 256 || (dens >> 16) > 256 || !grid) return 1;
   scene_t s;
   int rc = scene_setup(&s, N, seed, amp_num, dens);
   if (rc) { free_scene(&s); return rc; }

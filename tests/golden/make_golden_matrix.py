@@ -3,8 +3,8 @@
 rendered by the reference shader itself under llvmpipe (oracle/_ref/llvmpipe_ref, shader read from /root/reference at run
 time), at the benchmark's full size: 8192^3, 1920x1080, renderMode 0, primary + 1 bounce.  Every STEP-th pixel in x and y of
 colour, depth and the first cast's hit record is kept; the pools are not stored (the generators are deterministic; a CRC
-catches drift).  Plus the new scene family ("caves", scene/svo_scene.c family 1) at 128^3 and 256^3 with the pools stored, full
-images, every render mode.  K0 and K1 over the default terrain are already in config3_8192.npz.
+catches drift).  Plus the new scene family ("caves", scene/svo_scene.c family 1) at 128^3 and 256^3 and the hostile one ("dust", family 2: floating
+particles) at 128^3 with the pools stored, full images, every render mode.  K0 and K1 over the default terrain are already in config3_8192.npz.
 Runs only in the build container.   python tests/golden/make_golden_matrix.py"""
 import os
 import struct
@@ -26,14 +26,15 @@ SHADER = "/root/reference/src/shaders/svotrace.comp"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_ref")
 STEP = 8
 # scene key: (family, seed, amp, dens)
-SCENES = {"t1a8": ("terrain", 1, 8, 0), "t2a18": ("terrain", 2, 18, 0), "c1a8d64": ("caves", 1, 8, 64)}
+SCENES = {"t1a8": ("terrain", 1, 8, 0), "t2a18": ("terrain", 2, 18, 0), "c1a8d64": ("caves", 1, 8, 64), "d1a8x24": ("dust", 1, 8, 24)}
 # full size: name, scene, camera, frameNumber, renderMode
 FULL = [("t1a8_K2_f2", "t1a8", "K2", 2, 0),
         ("t2a18_K0_f2", "t2a18", "K0", 2, 0), ("t2a18_K1_f2", "t2a18", "K1", 2, 0), ("t2a18_K2_f5", "t2a18", "K2", 5, 0),
         ("c1a8d64_K0_f2", "c1a8d64", "K0", 2, 0), ("c1a8d64_K1_f2", "c1a8d64", "K1", 2, 0), ("c1a8d64_K2_f2", "c1a8d64", "K2", 2, 0),
-        ("c1a8d64_K1_m2", "c1a8d64", "K1", 2, 2), ("c1a8d64_CAVE_f2", "c1a8d64", "CAVE", 2, 0)]
+        ("c1a8d64_K1_m2", "c1a8d64", "K1", 2, 2), ("c1a8d64_CAVE_f2", "c1a8d64", "CAVE", 2, 0),
+        ("d1a8x24_K0_f2", "d1a8x24", "K0", 2, 0), ("d1a8x24_K1_f2", "d1a8x24", "K1", 2, 0), ("d1a8x24_K2_f2", "d1a8x24", "K2", 2, 0)]
 # small, pools stored: pool key -> (n, seed, amp, dens)
-SMALL_POOLS = {"c128": (128, 1, 8, 64), "c256": (256, 2, 8, 128)}
+SMALL_POOLS = {"c128": (128, 1, 8, 64), "c256": (256, 2, 8, 128), "d128": (128, 1, 8, 64 << 16)}     # (bits 16..: the dust level's density)
 
 
 def cam_line(cam):
@@ -52,7 +53,7 @@ def main():
     # ---- the new family, small, every mode, full images, patched == plain checked
     small = []
     for pk, (n, seed, amp, dens) in SMALL_POOLS.items():
-        pool, _ = scene.build_scene3(n, seed, amp, dens)
+        pool, _ = scene.build_scene3(n, seed, amp, dens & 0xffff, dens >> 16)
         out["pool/" + pk] = pool
         path = os.path.join(tmp, pk + ".bin")
         pool.tofile(path)
@@ -79,7 +80,7 @@ def main():
     W, H = 1920, 1080
     for sk, (family, seed, amp, dens) in SCENES.items():
         cases = [c for c in FULL if c[1] == sk]
-        pool, _ = scene.build(family, 8192, seed, amp, dens)
+        pool, _ = scene.build(family, 8192, seed, amp, dens, dens)
         path = os.path.join(tmp, sk + ".bin")
         pool.tofile(path)
         out[sk + "/pool_crc32"] = np.array([zlib.crc32(pool.tobytes())], dtype=np.uint32)

@@ -8,11 +8,11 @@ _cache = collections.OrderedDict()
 
 
 def pool(family="terrain", n=8192, seed=1, amp=8, dens=scene.CAVES_DENS):
-    key = (family, n, seed, amp, dens if family == "caves" else 0)
+    key = (family, n, seed, amp, dens if family != "terrain" else 0)
     if key in _cache:
         _cache.move_to_end(key)
         return _cache[key]
-    p, _ = scene.build(family, n, seed, amp, dens)
+    p, _ = scene.build(family, n, seed, amp, dens, dens)      # (dens: the caves' density or the dust's, by family)
     p.setflags(write=False)
     _cache[key] = p
     while len(_cache) > 2:

@@ -34,7 +34,7 @@ def _full(scene_key):
     return [n for n, sk in (str(s).split(":") for s in Z()["index_full"]) if sk == scene_key]
 
 
-SCENE_KEYS = ["t1a8", "t2a18", "c1a8d64"]
+SCENE_KEYS = ["t1a8", "t2a18", "c1a8d64", "d1a8x24"]
 
 
 @pytest.fixture(scope="module", params=SCENE_KEYS)

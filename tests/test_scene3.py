@@ -63,3 +63,29 @@ def test_pool_validates_and_is_deterministic(n, depth):
         p0, _ = scene.build_scene3(n, 1, 8, 0)
         t0, _ = scene.build_scene(n, 1, 8)
         assert p0.size == t0.size and (p0 == t0).all()
+
+
+@pytest.mark.parametrize("n,seed,dens,dust", [(32, 1, 0, 64), (64, 2, 0, 128), (128, 1, 0, 64), (128, 2, 64, 64)])
+def test_dust_family_matches_dense_brute_force_builder(n, seed, dens, dust):
+    """family 2: floating particles (radius 1 or 2 in air cells of edge max(8, n / 256)), alone and on top of the caves' balls"""
+    pool, st = scene.build_scene3(n, seed, 8, dens, dust)
+    grid = scene.scene3_voxels(n, seed, 8, dens, dust)
+    ref, counts = poolbuilder.pool_from_grid(grid)
+    assert pool.size == ref.size and (pool == ref).all()
+    base = scene.scene3_voxels(n, seed, 8, dens, 0) if dens else poolbuilder.terrain_grid(n, seed, 8)
+    added = (grid != 0) & (base == 0)
+    assert added.sum() > 100 and not ((grid == 0) & (base != 0)).any()      # dust only adds, in the air
+    if dens:
+        return      # (over curved ball surfaces the six axis probes of a particle do not rule out every contact)
+    # a particle floats: over the terrain alone no added voxel touches a voxel of the scene it was added to (6-neighbourhood)
+    solid = base != 0
+    touch = np.zeros_like(solid)
+    for ax in range(3):
+        for sh in (1, -1):
+            r = np.roll(solid, sh, axis=ax)
+            idx = [slice(None)] * 3
+            idx[ax] = 0 if sh == 1 else -1
+            r[tuple(idx)] = False
+            touch |= r
+    assert not (added & touch).any()
+    assert sum(b for _, b in scene.scene3_ball_counts(n, seed, 8, dens, dust)) > 0

@@ -14,9 +14,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCENES = {"t1a8": ("terrain", 1, 8), "t2a18": ("terrain", 2, 18), "c1a8d64": ("caves", 1, 8)}
+SCENES = {"t1a8": ("terrain", 1, 8), "t2a18": ("terrain", 2, 18), "c1a8d64": ("caves", 1, 8), "d1a8x24": ("dust", 1, 8)}
 SCENE_TEXT = {"t1a8": "terrain, seed 1, amplitude 8/16 (rounds 1-5)", "t2a18": "terrain, seed 2, amplitude 18/16",
-              "c1a8d64": "caves: terrain seed 1 + hashed balls (dens 64/256)"}
+              "c1a8d64": "caves: terrain seed 1 + hashed balls (dens 64/256)",
+              "d1a8x24": "dust: terrain seed 1 + floating particles (24/256 of the air cells)"}
 CAMS = ("K0", "K1", "K2")
 BENCH = ["--steps", "400", "--warmup", "24", "--long-steps", "0", "--moving", "0", "--default-abi", "0", "--by-camera", "0", "--ref-loop", "1", "--cpu-seconds", "0"]
 

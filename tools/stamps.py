@@ -4,11 +4,12 @@ import numpy as np
 import svo_raytracer_amd.scene as scene
 from svo_raytracer_amd import hiplib
 from svo_raytracer_amd.cameras import CAMERAS
-# the cell: STAMPS_SCENE = terrain | caves, STAMPS_SEED, STAMPS_AMP, STAMPS_CAMERA = K0 | K1 | K2 (default: the bench line's)
+# the cell: STAMPS_SCENE = terrain | caves | dust, STAMPS_SEED, STAMPS_AMP, STAMPS_CAMERA = K0 | K1 | K2 (default: the bench line's)
 SCENE, SEED, AMP = os.environ.get("STAMPS_SCENE", "terrain"), int(os.environ.get("STAMPS_SEED", "1")), int(os.environ.get("STAMPS_AMP", "8"))
 CAMERA = os.environ.get("STAMPS_CAMERA", "K1")
 CELL = "%s_s%d_a%d_%s" % (SCENE, SEED, AMP, CAMERA)
-_cache = os.environ.get("SVO_SCENE_CACHE") and os.path.join(os.environ["SVO_SCENE_CACHE"], "caves_8192_s%d_a%d_d%d.npy" % (SEED, AMP, scene.CAVES_DENS))
+_cache = os.environ.get("SVO_SCENE_CACHE") and os.path.join(os.environ["SVO_SCENE_CACHE"], "%s_8192_s%d_a%d_d%d.npy" % (
+    SCENE, SEED, AMP, scene.DUST_DENS if SCENE == "dust" else scene.CAVES_DENS))
 ctx = hiplib.HipContext(0)
 if SCENE == "terrain":      # on the GPU from its two maps, as bench.py does
     ctx.build_from_heightmap(*scene.scene_maps(8192, SEED, AMP))
