@@ -164,7 +164,10 @@ int svo_set_pipeline(svo_ctx *ctx, int pipeline);
  * time); svo_dispatch_async while it takes turns on n image sets takes about 32 / n (4 sets: 8); the
  * submissions of a ring with more than one slot (svo_ring_create / svo_group_ring_create) take 10 per launch, so that the next
  * launch's waves find CU slots while the previous launch drains -- the shape bench.py's headline is measured on, without any
- * call.  A positive value is used as given everywhere (a caller that alternates its own streams with svo_set_stream: ~10). */
+ * call.  A positive value is used as given everywhere (a caller that alternates its own streams with svo_set_stream: ~10).
+ * The threshold 9 is the optimum of the bench scenes (8: -0.6 % on the default cell, -1.4 % on the worst terrain cell); scenes
+ * whose rays take hundreds of iterations -- the "dust" cells of profiles/round6_matrix.md -- prefer 8 by 1.4 ... 3.5 %
+ * (profiles/round6_sweep_hostile_cell.md): a host that renders such scenes calls svo_set_tuning(ctx, 0, 8). */
 int svo_set_tuning(svo_ctx *ctx, int waves_per_cu, int round_threshold_sixteenths);
 /* shape of the last pipeline-1 launch of the context: persistent waves launched, waves per CU they were sized by, round
  * threshold in sixteenths (any pointer may be NULL).  Diagnostic: what svo_set_tuning's automatic choice resolved to. */
