@@ -252,7 +252,7 @@ int svo_dispatch_async(svo_ctx *ctx);
  *     batches, accumulation, several samples per pixel, the beam pre-pass) or a negative x (= no pick) take the waiting path:
  *     same values either way (tests/test_gpu_pick.py). */
 int svo_set_pick(svo_ctx *ctx, int x, int y);
-int svo_set_overlap(svo_ctx *ctx, int enabled);
+int svo_set_overlap(svo_ctx *ctx, int sets);   /* 0 = one set, 1 = the default (4), 2 .. 8 = that many */
 /* the pick position in force (-1, -1: none) and how many svo_read_pixel calls were answered from the mail / by waiting for
  * their frame since the context was made.  Any pointer may be NULL. */
 int svo_pick_info(svo_ctx *ctx, int *x, int *y, uint64_t *from_mail, uint64_t *waited);

@@ -72,7 +72,7 @@ jint Java_src_engine_HipRenderer_nSetProgressive(void *env, void *cls, jlong ctx
 jint Java_src_engine_HipRenderer_nDispatchAsync(void *env, void *cls, jlong ctx);
 jint Java_src_engine_HipRenderer_nSync(void *env, void *cls, jlong ctx);
 jint Java_src_engine_HipRenderer_nSetPick(void *env, void *cls, jlong ctx, jint x, jint y);       /* svo_set_pick */
-jint Java_src_engine_HipRenderer_nSetOverlap(void *env, void *cls, jlong ctx, jint enabled);     /* svo_set_overlap */
+jint Java_src_engine_HipRenderer_nSetOverlap(void *env, void *cls, jlong ctx, jint sets);        /* svo_set_overlap: 0, 1, 2 .. 8 */
 /* svo_pick_info: read-backs answered from the mail (or a negative status); two ints (x, y of the pick in force) at xy_addr and
  * the read-backs that waited for their frame at waited_addr (a long) unless 0 */
 jlong Java_src_engine_HipRenderer_nPickInfo(void *env, void *cls, jlong ctx, jlong xy_addr, jlong waited_addr);

@@ -625,7 +625,7 @@ public class HipRenderer {
   private static native int nDispatchAsync(long ctx);
   private static native int nSync(long ctx);
   private static native int nSetPick(long ctx, int x, int y);
-  private static native int nSetOverlap(long ctx, int enabled);
+  private static native int nSetOverlap(long ctx, int sets);
   private static native long nPickInfo(long ctx, long xyAddr, long waitedAddr);
   private static native int nSetStream(long ctx, long hipStream);
   private static native int nSetPipeline(long ctx, int pipeline);

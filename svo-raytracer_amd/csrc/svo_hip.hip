@@ -662,11 +662,11 @@ int svo_set_stream(svo_ctx *c, void *hip_stream) {
   return SVO_OK;
 }
 
-int svo_set_overlap(svo_ctx *c, int enabled) {
+int svo_set_overlap(svo_ctx *c, int sets) {
   if (!c) return SVO_E_INVALID;
   // 0: one set (no alternation); 1: the default number of sets; 2 .. 4: that many
-  if (enabled < 0 || enabled > svo_ctx::kMaxSets) return fail(c, SVO_E_INVALID, "svo_set_overlap: 0 (off), 1 (the default number of sets) or 2 .. 8 sets");
-  c->overlap = enabled == 0 ? 1 : (enabled == 1 ? 4 : enabled);
+  if (sets < 0 || sets > svo_ctx::kMaxSets) return fail(c, SVO_E_INVALID, "svo_set_overlap: 0 (off), 1 (the default number of sets) or 2 .. 8 sets");
+  c->overlap = sets == 0 ? 1 : (sets == 1 ? 4 : sets);
   return SVO_OK;
 }
 

@@ -84,7 +84,7 @@ jint Java_src_engine_HipRenderer_nSetProgressive(void *, void *, jlong ctx, jint
 jint Java_src_engine_HipRenderer_nDispatchAsync(void *, void *, jlong ctx) { return svo_dispatch_async(CTX(ctx)); }
 jint Java_src_engine_HipRenderer_nSync(void *, void *, jlong ctx) { return svo_sync(CTX(ctx)); }
 jint Java_src_engine_HipRenderer_nSetPick(void *, void *, jlong ctx, jint x, jint y) { return svo_set_pick(CTX(ctx), x, y); }
-jint Java_src_engine_HipRenderer_nSetOverlap(void *, void *, jlong ctx, jint enabled) { return svo_set_overlap(CTX(ctx), enabled); }
+jint Java_src_engine_HipRenderer_nSetOverlap(void *, void *, jlong ctx, jint sets) { return svo_set_overlap(CTX(ctx), sets); }
 jlong Java_src_engine_HipRenderer_nPickInfo(void *, void *, jlong ctx, jlong xy_addr, jlong waited_addr) {
   int xy[2] = {-1, -1};
   uint64_t from_mail = 0, waited = 0;
