@@ -89,3 +89,26 @@ def test_dust_family_matches_dense_brute_force_builder(n, seed, dens, dust):
             touch |= r
     assert not (added & touch).any()
     assert sum(b for _, b in scene.scene3_ball_counts(n, seed, 8, dens, dust)) > 0
+
+
+def test_cave_camera_sits_in_carved_air_away_from_the_world_faces():
+    """cameras.cave_camera / scene.cave_position (bench.py --camera CAVE): the centre of the largest carving ball of the coarsest
+    level that has one, not at a world face -- a voxel the balls emptied, with solid terrain around the cave"""
+    from svo_raytracer_amd.cameras import cave_camera
+    n = 256
+    pos, r = scene.cave_position(n, 1, 8, 64)
+    g = scene.scene3_voxels(n, 1, 8, 64)
+    t = poolbuilder.terrain_grid(n, 1, 8)
+    x, y, z = (int((p - 1.0) * n) for p in pos)
+    assert g[z, y, x] == 0 and t[z, y, x] != 0                      # carved out of what was solid
+    assert all(2 * r <= c < n - 2 * r for c in (x, y, z))
+    cam = cave_camera(n, 1, 8, 64)
+    assert cam.shape == (15,) and np.allclose(cam[:3], pos)
+    assert (cave_camera(n, 1, 8, 64) == cam).all()
+    # the scene's balls, as listed: every ball inside its cell, carving ones where the coarser scene is solid
+    b = scene.scene3_balls(n, 1, 8, 64)
+    assert len(b) == sum(a + s for a, s in scene.scene3_ball_counts(n, 1, 8, 64))
+    for lvl, cx, cy, cz, rr, val in b[:200]:
+        C = n >> (2 + 2 * lvl)
+        for c in (cx, cy, cz):
+            assert (c - rr) // C == (c + rr) // C == c // C
