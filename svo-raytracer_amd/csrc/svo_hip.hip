@@ -905,14 +905,24 @@ static int launch_pick(svo_ctx *c) {
   int rc = make_frame(c, f);
   if (rc) return rc;
   if (f.ntiles <= 0 || c->pick_x >= f.width || c->pick_y >= f.height) return SVO_OK;
+  // (the pick is a convenience: a runtime that cannot give it its mail or its stream leaves every read-back on the waiting path)
   if (!c->pick_mail) {
-    HIPCHK(c, hipHostMalloc((void **)&c->pick_mail, (size_t)kPickSlots * kPickWords * sizeof(uint32_t), hipHostMallocCoherent));
+    if (hipHostMalloc((void **)&c->pick_mail, (size_t)kPickSlots * kPickWords * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess) {
+      c->pick_mail = nullptr;
+      (void)hipGetLastError();
+      return SVO_OK;
+    }
     memset(c->pick_mail, 0, (size_t)kPickSlots * kPickWords * sizeof(uint32_t));
   }
   if (!c->pick_stream) {
-    int lo = 0, hi = 0;
-    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (hi = the greatest priority = the numerically lowest value)
-    HIPCHK(c, hipStreamCreateWithPriority(&c->pick_stream, hipStreamNonBlocking, hi));
+    int lo = 0, hi = 0;   // (hi = the greatest priority = the numerically lowest value)
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) hi = 0;
+    if (hipStreamCreateWithPriority(&c->pick_stream, hipStreamNonBlocking, hi) != hipSuccess &&
+        hipStreamCreateWithFlags(&c->pick_stream, hipStreamNonBlocking) != hipSuccess) {
+      c->pick_stream = nullptr;
+      (void)hipGetLastError();
+      return SVO_OK;
+    }
   }
   const uint32_t seq = c->pick_seq + 1u == 0u ? 1u : c->pick_seq + 1u;   // (0 = "nothing written yet")
   uint32_t *mail = c->pick_mail + (size_t)(seq % (uint32_t)kPickSlots) * kPickWords;
